@@ -1,0 +1,139 @@
+/*
+ * smartgpu.h — C ABI of the MI355X exact-string-matching engine that sits
+ * behind SMART's per-algorithm plugin surface.
+ *
+ * Drop-in boundary.  Each entry point names the reference
+ * interface it replaces (paths relative to the SMART tree):
+ *
+ *   reference                                      this library
+ *   ---------------------------------------------  ---------------------------------
+ *   int search(unsigned char*,int,unsigned char*,  smartgpu_<algo>_search()   (same shape,
+ *       int)          src/algos/include/main.h:39    same return convention: count, -1 = n/a)
+ *   double *run_time,*pre_time (ms, written by the  smartgpu_last_times(), and the pre_ms /
+ *       BEGIN_/END_ macros)   main.h:28-31,34-35    run_ms out-params of smartgpu_search64()
+ *   text in a SysV segment: shmget(tkey,TSIZE+10)   smartgpu_text_upload()/_generate()/_free():
+ *       + getText()    src/smart.c:553-568,95-138    the text lives in HBM for a whole run
+ *   execute(): system("./source/bin/<algo> shared   smartgpu_search64() — an in-process call
+ *       ...")          src/smart.c:140-146           instead of a process spawn per pattern
+ *   textgen rand-sigma corpora  src/textgen.c:34-54 smartgpu_text_generate() (on-device,
+ *                                                    counter-based)
+ *
+ * All pointers are plain host pointers unless a parameter says "device"; there
+ * are no C++ or torch types in any signature.  The library is single-threaded
+ * from the caller's point of view (like SMART); every call that returns a count
+ * is synchronous.  Errors: negative return codes, text in smartgpu_last_error().
+ *
+ * There is no CPU fallback: without a usable HIP device every compute entry
+ * point fails with SMARTGPU_ERR_HIP.
+ */
+#ifndef SMARTGPU_H
+#define SMARTGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMARTGPU_XSIZE 4200 /* longest pattern, src/algos/include/define.h:25 */
+
+/* return codes (SMART keeps count>=0 / -1 "not applicable"; src/smart.c:143-145,330-343) */
+#define SMARTGPU_OK 0
+#define SMARTGPU_NA (-1)          /* algorithm not applicable / count does not fit an int */
+#define SMARTGPU_ERR_ARG (-3)     /* bad argument (unknown algorithm, m<1, m>XSIZE, range) */
+#define SMARTGPU_ERR_HIP (-4)     /* HIP runtime error or no device */
+#define SMARTGPU_ERR_NOMEM (-5)
+
+/* algorithm ids; names are SMART's lower-case executable names (src/smart.c:142) */
+enum {
+    SMARTGPU_HOR = 0,  /* src/algos/hor.c  */
+    SMARTGPU_BM = 1,   /* src/algos/bm.c   */
+    SMARTGPU_KMP = 2,  /* src/algos/kmp.c  */
+    SMARTGPU_SO = 3,   /* src/algos/so.c   */
+    SMARTGPU_BNDM = 4, /* src/algos/bndm.c */
+    SMARTGPU_EPSM = 5, /* src/algos/epsm.c */
+    SMARTGPU_NUM_ALGOS = 6
+};
+
+typedef struct smartgpu_text smartgpu_text; /* a text resident in one GPU's HBM */
+typedef struct smartgpu_plan smartgpu_plan; /* one (algorithm, pattern) with its tables in HBM */
+
+/* ---- library ---------------------------------------------------------- */
+const char *smartgpu_version(void);
+const char *smartgpu_last_error(void);
+int smartgpu_device_count(void);                   /* <0 on error */
+int smartgpu_algo_id(const char *name);            /* "hor","bm","kmp","so","bndm","epsm" (any case); -1 unknown */
+const char *smartgpu_algo_name(int algo);          /* NULL if out of range */
+int smartgpu_device_sync(int device);              /* waits for the library's stream on `device` */
+
+/* ---- text lifecycle (replaces shmget + getText, src/smart.c:553-568,95-138) ---- */
+/* Copies host[0..n) into HBM of `device` through pinned staging.  NULL on error. */
+smartgpu_text *smartgpu_text_upload(const void *host, uint64_t n, int device);
+/* Text byte i = unit[(phase + i) % unit_len] for i in [0,n): a corpus replicated
+ * to a target size (BASELINE config 4) without shipping n bytes over PCIe. */
+smartgpu_text *smartgpu_text_upload_tiled(const void *unit, uint64_t unit_len, uint64_t phase,
+                                          uint64_t n, int device);
+/* Text byte i = byte (off+i) of the counter-based rand-sigma corpus, generated on
+ * the device: splitmix64(seed + (j>>3)) >> (8*(j&7)), masked (sigma a power of
+ * two) or reduced modulo sigma.  2 <= sigma <= 256. */
+smartgpu_text *smartgpu_text_generate(uint64_t seed, int sigma, uint64_t off, uint64_t n, int device);
+void smartgpu_text_free(smartgpu_text *t);
+uint64_t smartgpu_text_length(const smartgpu_text *t);
+int smartgpu_text_device(const smartgpu_text *t);
+/* Copies text[off..off+len) back to the host (tests, pattern extraction à la
+ * setOfRandomPatterns, src/smart.c:148-158). */
+int smartgpu_text_read(const smartgpu_text *t, uint64_t off, uint64_t len, void *host);
+
+/* ---- searching -------------------------------------------------------- */
+/* Counts the occurrences of P[0..m) whose window lies inside text[off..off+n),
+ * i.e. start positions s in [off, off+n-m].  Overlapping occurrences count
+ * (define.h:33).  *pre_ms = host table construction + table upload
+ * (BEGIN_/END_PREPROCESSING, main.h:28,30); *run_ms = kernel(s) + count readback,
+ * by HIP events (BEGIN_/END_SEARCHING, main.h:29,31).  Either may be NULL. */
+int smartgpu_search64(int algo, const uint8_t *P, uint32_t m, const smartgpu_text *text,
+                      uint64_t off, uint64_t n, uint64_t *count, double *pre_ms, double *run_ms);
+
+/* SMART's own plugin shape, one symbol per algorithm (main.h:39).  T is a HOST
+ * pointer: the text is uploaded for the call and released afterwards, so this
+ * is the compatibility path, not the fast one.  Returns the count, or -1 when
+ * it does not fit an int / on error (smart.c:143-145 maps any failure to -1). */
+int smartgpu_hor_search(const unsigned char *P, int m, const unsigned char *T, int n);
+int smartgpu_bm_search(const unsigned char *P, int m, const unsigned char *T, int n);
+int smartgpu_kmp_search(const unsigned char *P, int m, const unsigned char *T, int n);
+int smartgpu_so_search(const unsigned char *P, int m, const unsigned char *T, int n);
+int smartgpu_bndm_search(const unsigned char *P, int m, const unsigned char *T, int n);
+int smartgpu_epsm_search(const unsigned char *P, int m, const unsigned char *T, int n);
+/* pre/run times (ms) of the last search on this thread (main.h:34-35 globals) */
+void smartgpu_last_times(double *pre_ms, double *run_ms);
+
+/* ---- plans: preprocess once, launch many (harness hot loop, smart.c:312-345) ---- */
+/* Builds the algorithm's tables on the host and places them in HBM of `device`. */
+smartgpu_plan *smartgpu_plan_create(int algo, const uint8_t *P, uint32_t m, int device);
+void smartgpu_plan_free(smartgpu_plan *p);
+/* Enqueues one search of text[off..off+n) on the device's stream and returns
+ * without waiting; the count goes to result slot `slot` (0 <= slot < 4096) of
+ * the plan.  With `timed` != 0 the launch is bracketed by HIP events. */
+int smartgpu_plan_launch(smartgpu_plan *p, const smartgpu_text *text, uint64_t off, uint64_t n,
+                         int slot, int timed);
+/* Waits for the stream and returns the count of `slot` (and, if the launch was
+ * timed, its device time in ms; else *kernel_ms = -1). */
+int smartgpu_plan_result(smartgpu_plan *p, int slot, uint64_t *count, double *kernel_ms);
+/* Name of the dominant kernel the plan launches (as rocprofv3 reports it). */
+const char *smartgpu_plan_kernel_name(const smartgpu_plan *p);
+/* Device address of the plan's 4096 uint64 result slots (for an RCCL reduce
+ * issued by the caller on the same device). */
+void *smartgpu_plan_result_device_ptr(smartgpu_plan *p);
+
+/* Host-side preprocessing exposed for tests (same tables the kernels stage in
+ * LDS): writes up to `cap` 32-bit entries, returns the number written or <0.
+ *   which: 0 Horspool bad-char (256)      hor.c:26-30 / bm.c:27-33
+ *          1 BM good-suffix (m)           bm.c:36-66
+ *          2 KMP failure function (m+1)   kmp.c:27-41
+ *          3 Shift-Or masks (256)         so.c:27-38   (32-bit words, prefix of 32 for m>32)
+ *          4 BNDM masks (256)             bndm.c:35-40 (same)                                  */
+int smartgpu_build_table(int which, const uint8_t *P, uint32_t m, int32_t *out, uint32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMARTGPU_H */

@@ -1,0 +1,510 @@
+// api.cpp — C ABI of libsmartgpu (include/smartgpu.h): text residency in HBM,
+// host-side preprocessing, launches, timing.  Compiled with hipcc as host code.
+//
+// There is deliberately no CPU search path in this file or anywhere in the
+// library: if HIP is not usable every compute entry point fails.
+#include "../../include/smartgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "tables.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+thread_local double g_last_pre_ms = 0.0, g_last_run_ms = 0.0;
+
+void set_error(const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+#define HIP_TRY(expr, fail)                                                          \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            fail;                                                                    \
+        }                                                                            \
+    } while (0)
+
+constexpr int kMaxDevices = 16;
+
+struct DeviceCtx {
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    uint8_t* pinned = nullptr;      // staging for uploads
+    size_t pinned_bytes = 0;
+    unsigned long long* pinned_count = nullptr;  // 8-byte readback slot
+};
+DeviceCtx g_dev[kMaxDevices];
+
+DeviceCtx* device_ctx(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device available (hipGetDeviceCount)");
+        return nullptr;
+    }
+    if (device < 0 || device >= n || device >= kMaxDevices) {
+        set_error("device %d out of range (have %d)", device, n);
+        return nullptr;
+    }
+    DeviceCtx& d = g_dev[device];
+    HIP_TRY(hipSetDevice(device), return nullptr);
+    if (!d.ready) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device), return nullptr);
+        d.num_cus = prop.multiProcessorCount;
+        HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking), return nullptr);
+        d.pinned_bytes = 32u << 20;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d.pinned), d.pinned_bytes, hipHostMallocDefault),
+                return nullptr);
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d.pinned_count), 64, hipHostMallocDefault),
+                return nullptr);
+        d.ready = true;
+    }
+    return &d;
+}
+
+double now_ms()
+{
+    using clk = std::chrono::steady_clock;  // CLOCK_MONOTONIC, as src/timer.h:43-55
+    return std::chrono::duration<double, std::milli>(clk::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct smartgpu_text {
+    int device = 0;
+    uint64_t n = 0;
+    uint8_t* base = nullptr;  // allocation start; text byte 0 at base + kFrontPad
+    const uint8_t* data() const { return base + sg::kFrontPad; }
+};
+
+struct smartgpu_plan {
+    int device = 0;
+    int algo = 0;
+    uint32_t m = 0;
+    uint32_t halo = 0;
+    uint8_t* blob = nullptr;               // device: pattern + tables
+    unsigned long long* results = nullptr; // device: kResultSlots counters
+    hipEvent_t ev0[sg::kResultSlots] = {}; // created lazily for timed launches
+    hipEvent_t ev1[sg::kResultSlots] = {};
+    bool timed[sg::kResultSlots] = {};
+    double pre_ms = 0.0;
+};
+
+namespace {
+
+const char* kAlgoNames[SMARTGPU_NUM_ALGOS] = {"hor", "bm", "kmp", "so", "bndm", "epsm"};
+
+smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
+{
+    DeviceCtx* d = device_ctx(device);
+    if (!d) return nullptr;
+    smartgpu_text* t = new smartgpu_text;
+    t->device = device;
+    t->n = n;
+    const uint64_t total = sg::kFrontPad + n + sg::kBackPad;
+    if (hipMalloc(reinterpret_cast<void**>(&t->base), total) != hipSuccess) {
+        set_error("hipMalloc of %llu bytes failed", (unsigned long long)total);
+        delete t;
+        return nullptr;
+    }
+    // pads are zero; they are never counted as text, only read by whole-tile loads
+    if (hipMemsetAsync(t->base, 0, sg::kFrontPad, d->stream) != hipSuccess ||
+        hipMemsetAsync(t->base + sg::kFrontPad + n, 0, sg::kBackPad, d->stream) != hipSuccess) {
+        set_error("hipMemsetAsync of the text pads failed");
+        hipFree(t->base);
+        delete t;
+        return nullptr;
+    }
+    *ctx_out = d;
+    return t;
+}
+
+// Build the device blob (pattern + tables) for (algo, P, m) in a host vector.
+std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t* halo)
+{
+    std::vector<uint8_t> blob(sg::kPatternBytes, 0);
+    std::memcpy(blob.data(), P, m);
+    auto append = [&blob](const void* p, size_t bytes) {
+        const uint8_t* b = static_cast<const uint8_t*>(p);
+        blob.insert(blob.end(), b, b + bytes);
+    };
+    *halo = std::min<uint32_t>(m - 1, sg::kHaloMax);
+    switch (algo) {
+        case SMARTGPU_HOR: {
+            const std::vector<int32_t> bc = sg::bad_char(P, m);
+            std::vector<uint16_t> tab(256);
+            for (int c = 0; c < 256; ++c)
+                tab[c] = static_cast<uint16_t>(bc[c]) | (c == P[m - 1] ? 0x8000u : 0u);
+            append(tab.data(), 512);
+            break;
+        }
+        case SMARTGPU_BM: {
+            const std::vector<int32_t> bc = sg::bad_char(P, m);
+            const std::vector<int32_t> gs = sg::good_suffix(P, m);
+            std::vector<uint16_t> tab(256 + m);
+            for (int c = 0; c < 256; ++c) tab[c] = static_cast<uint16_t>(bc[c]);
+            for (uint32_t i = 0; i < m; ++i) tab[256 + i] = static_cast<uint16_t>(gs[i]);
+            append(tab.data(), tab.size() * 2);
+            break;
+        }
+        case SMARTGPU_KMP: {
+            const std::vector<int32_t> nx = sg::kmp_next(P, m);
+            std::vector<int16_t> tab(m + 1);
+            for (uint32_t i = 0; i <= m; ++i) tab[i] = static_cast<int16_t>(nx[i]);
+            append(tab.data(), tab.size() * 2);
+            *halo = m - 1;  // forward halo: the automaton re-scans m-1 bytes
+            break;
+        }
+        case SMARTGPU_SO: {
+            const std::vector<uint32_t> S = sg::shift_or_masks(P, m);
+            append(S.data(), 1024);
+            break;
+        }
+        case SMARTGPU_BNDM: {
+            const std::vector<uint32_t> B = sg::bndm_masks(P, m);
+            append(B.data(), 1024);
+            break;
+        }
+        case SMARTGPU_EPSM: {
+            uint32_t fp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            uint8_t* fb = reinterpret_cast<uint8_t*>(fp);
+            const uint32_t F = std::min<uint32_t>(m, 16);
+            for (uint32_t i = 0; i < F; ++i) {
+                fb[i] = P[i];
+                fb[16 + i] = 0xFF;
+            }
+            append(fp, sizeof fp);
+            break;
+        }
+    }
+    blob.resize((blob.size() + 255) & ~size_t(255), 0);
+    return blob;
+}
+
+int check_search_args(int algo, const uint8_t* P, uint32_t m, const smartgpu_text* text,
+                      uint64_t off, uint64_t n)
+{
+    if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS) { set_error("unknown algorithm id %d", algo); return SMARTGPU_ERR_ARG; }
+    if (!P || m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return SMARTGPU_ERR_ARG; }
+    if (!text) { set_error("text handle is NULL"); return SMARTGPU_ERR_ARG; }
+    if (off > text->n || n > text->n - off) { set_error("range [%llu,+%llu) outside the text (%llu bytes)", (unsigned long long)off, (unsigned long long)n, (unsigned long long)text->n); return SMARTGPU_ERR_ARG; }
+    return SMARTGPU_OK;
+}
+
+sg::ScanArgs make_args(const smartgpu_plan* p, const smartgpu_text* text, uint64_t off, uint64_t n,
+                       int slot)
+{
+    sg::ScanArgs a;
+    a.text = text->data();
+    a.s_begin = off;
+    a.s_end = (n >= p->m) ? off + n - p->m + 1 : off;  // no window fits: empty range
+    a.m = p->m;
+    a.halo = p->halo;
+    a.blob = p->blob;
+    a.count = p->results + slot;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* smartgpu_version(void) { return "smartgpu 0.1 (gfx950)"; }
+const char* smartgpu_last_error(void) { return g_error.c_str(); }
+
+int smartgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { set_error("hipGetDeviceCount failed"); return SMARTGPU_ERR_HIP; }
+    return n;
+}
+
+int smartgpu_algo_id(const char* name)
+{
+    if (!name) return -1;
+    std::string s(name);
+    for (auto& ch : s) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
+    for (int i = 0; i < SMARTGPU_NUM_ALGOS; ++i)
+        if (s == kAlgoNames[i]) return i;
+    return -1;
+}
+
+const char* smartgpu_algo_name(int algo)
+{
+    return (algo >= 0 && algo < SMARTGPU_NUM_ALGOS) ? kAlgoNames[algo] : nullptr;
+}
+
+int smartgpu_device_sync(int device)
+{
+    DeviceCtx* d = device_ctx(device);
+    if (!d) return SMARTGPU_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(d->stream), return SMARTGPU_ERR_HIP);
+    return SMARTGPU_OK;
+}
+
+/* ---- text ------------------------------------------------------------- */
+smartgpu_text* smartgpu_text_upload(const void* host, uint64_t n, int device)
+{
+    if (!host && n) { set_error("host pointer is NULL"); return nullptr; }
+    DeviceCtx* d = nullptr;
+    smartgpu_text* t = text_alloc(n, device, &d);
+    if (!t) return nullptr;
+    const uint8_t* src = static_cast<const uint8_t*>(host);
+    uint8_t* dst = t->base + sg::kFrontPad;
+    for (uint64_t done = 0; done < n;) {  // pinned staging -> HBM
+        const size_t chunk = static_cast<size_t>(std::min<uint64_t>(d->pinned_bytes, n - done));
+        std::memcpy(d->pinned, src + done, chunk);
+        if (hipMemcpyAsync(dst + done, d->pinned, chunk, hipMemcpyHostToDevice, d->stream) != hipSuccess ||
+            hipStreamSynchronize(d->stream) != hipSuccess) {
+            set_error("text upload failed at byte %llu", (unsigned long long)done);
+            smartgpu_text_free(t);
+            return nullptr;
+        }
+        done += chunk;
+    }
+    hipStreamSynchronize(d->stream);
+    return t;
+}
+
+smartgpu_text* smartgpu_text_upload_tiled(const void* unit, uint64_t unit_len, uint64_t phase,
+                                          uint64_t n, int device)
+{
+    if (!unit || unit_len == 0) { set_error("empty unit"); return nullptr; }
+    smartgpu_text* u = smartgpu_text_upload(unit, unit_len, device);
+    if (!u) return nullptr;
+    DeviceCtx* d = nullptr;
+    smartgpu_text* t = text_alloc(n, device, &d);
+    if (!t) { smartgpu_text_free(u); return nullptr; }
+    hipError_t e = sg::launch_tile_fill(t->base + sg::kFrontPad, u->data(), unit_len, phase % unit_len, n, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    smartgpu_text_free(u);
+    if (e != hipSuccess) {
+        set_error("tile_fill failed: %s", hipGetErrorString(e));
+        smartgpu_text_free(t);
+        return nullptr;
+    }
+    return t;
+}
+
+smartgpu_text* smartgpu_text_generate(uint64_t seed, int sigma, uint64_t off, uint64_t n, int device)
+{
+    if (sigma < 2 || sigma > 256) { set_error("sigma %d outside [2,256]", sigma); return nullptr; }
+    DeviceCtx* d = nullptr;
+    smartgpu_text* t = text_alloc(n, device, &d);
+    if (!t) return nullptr;
+    hipError_t e = sg::launch_generate(t->base + sg::kFrontPad, seed, sigma, off, n, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    if (e != hipSuccess) {
+        set_error("generate_text failed: %s", hipGetErrorString(e));
+        smartgpu_text_free(t);
+        return nullptr;
+    }
+    return t;
+}
+
+void smartgpu_text_free(smartgpu_text* t)
+{
+    if (!t) return;
+    if (t->base) {
+        hipSetDevice(t->device);
+        hipFree(t->base);
+    }
+    delete t;
+}
+
+uint64_t smartgpu_text_length(const smartgpu_text* t) { return t ? t->n : 0; }
+int smartgpu_text_device(const smartgpu_text* t) { return t ? t->device : -1; }
+
+int smartgpu_text_read(const smartgpu_text* t, uint64_t off, uint64_t len, void* host)
+{
+    if (!t || !host || off > t->n || len > t->n - off) { set_error("bad text_read range"); return SMARTGPU_ERR_ARG; }
+    DeviceCtx* d = device_ctx(t->device);
+    if (!d) return SMARTGPU_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(d->stream), return SMARTGPU_ERR_HIP);
+    HIP_TRY(hipMemcpy(host, t->data() + off, len, hipMemcpyDeviceToHost), return SMARTGPU_ERR_HIP);
+    return SMARTGPU_OK;
+}
+
+/* ---- plans ------------------------------------------------------------ */
+smartgpu_plan* smartgpu_plan_create(int algo, const uint8_t* P, uint32_t m, int device)
+{
+    if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS) { set_error("unknown algorithm id %d", algo); return nullptr; }
+    if (!P || m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return nullptr; }
+    DeviceCtx* d = device_ctx(device);
+    if (!d) return nullptr;
+    const double t0 = now_ms();
+    smartgpu_plan* p = new smartgpu_plan;
+    p->device = device;
+    p->algo = algo;
+    p->m = m;
+    const std::vector<uint8_t> blob = build_blob(algo, P, m, &p->halo);
+    bool ok = hipMalloc(reinterpret_cast<void**>(&p->blob), blob.size()) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&p->results), sizeof(unsigned long long) * sg::kResultSlots) == hipSuccess;
+    if (ok) {
+        std::memcpy(d->pinned, blob.data(), blob.size());
+        ok = hipMemcpyAsync(p->blob, d->pinned, blob.size(), hipMemcpyHostToDevice, d->stream) == hipSuccess &&
+             hipMemsetAsync(p->results, 0, sizeof(unsigned long long) * sg::kResultSlots, d->stream) == hipSuccess &&
+             hipStreamSynchronize(d->stream) == hipSuccess;
+    }
+    if (!ok) {
+        set_error("plan_create: device allocation or table upload failed (%s)", hipGetErrorString(hipGetLastError()));
+        smartgpu_plan_free(p);
+        return nullptr;
+    }
+    p->pre_ms = now_ms() - t0;
+    return p;
+}
+
+void smartgpu_plan_free(smartgpu_plan* p)
+{
+    if (!p) return;
+    hipSetDevice(p->device);
+    for (int i = 0; i < sg::kResultSlots; ++i) {
+        if (p->ev0[i]) hipEventDestroy(p->ev0[i]);
+        if (p->ev1[i]) hipEventDestroy(p->ev1[i]);
+    }
+    if (p->blob) hipFree(p->blob);
+    if (p->results) hipFree(p->results);
+    delete p;
+}
+
+int smartgpu_plan_launch(smartgpu_plan* p, const smartgpu_text* text, uint64_t off, uint64_t n,
+                         int slot, int timed)
+{
+    if (!p || !text) { set_error("plan or text is NULL"); return SMARTGPU_ERR_ARG; }
+    if (slot < 0 || slot >= sg::kResultSlots) { set_error("slot %d out of range", slot); return SMARTGPU_ERR_ARG; }
+    if (text->device != p->device) { set_error("plan is on device %d, text on %d", p->device, text->device); return SMARTGPU_ERR_ARG; }
+    if (off > text->n || n > text->n - off) { set_error("range outside the text"); return SMARTGPU_ERR_ARG; }
+    DeviceCtx* d = device_ctx(p->device);
+    if (!d) return SMARTGPU_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(p->results + slot, 0, sizeof(unsigned long long), d->stream), return SMARTGPU_ERR_HIP);
+    p->timed[slot] = timed != 0;
+    if (timed) {
+        if (!p->ev0[slot]) {
+            HIP_TRY(hipEventCreate(&p->ev0[slot]), return SMARTGPU_ERR_HIP);
+            HIP_TRY(hipEventCreate(&p->ev1[slot]), return SMARTGPU_ERR_HIP);
+        }
+        HIP_TRY(hipEventRecord(p->ev0[slot], d->stream), return SMARTGPU_ERR_HIP);
+    }
+    const sg::ScanArgs a = make_args(p, text, off, n, slot);
+    HIP_TRY(sg::launch_scan(p->algo, a, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
+    if (timed) HIP_TRY(hipEventRecord(p->ev1[slot], d->stream), return SMARTGPU_ERR_HIP);
+    return SMARTGPU_OK;
+}
+
+int smartgpu_plan_result(smartgpu_plan* p, int slot, uint64_t* count, double* kernel_ms)
+{
+    if (!p || slot < 0 || slot >= sg::kResultSlots) { set_error("bad plan/slot"); return SMARTGPU_ERR_ARG; }
+    DeviceCtx* d = device_ctx(p->device);
+    if (!d) return SMARTGPU_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(d->pinned_count, p->results + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, d->stream),
+            return SMARTGPU_ERR_HIP);
+    HIP_TRY(hipStreamSynchronize(d->stream), return SMARTGPU_ERR_HIP);
+    if (count) *count = *d->pinned_count;
+    if (kernel_ms) {
+        *kernel_ms = -1.0;
+        if (p->timed[slot]) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, p->ev0[slot], p->ev1[slot]), return SMARTGPU_ERR_HIP);
+            *kernel_ms = ms;
+        }
+    }
+    return SMARTGPU_OK;
+}
+
+const char* smartgpu_plan_kernel_name(const smartgpu_plan* p)
+{
+    return p ? sg::scan_kernel_name(p->algo, p->m) : nullptr;
+}
+
+void* smartgpu_plan_result_device_ptr(smartgpu_plan* p) { return p ? p->results : nullptr; }
+
+/* ---- one-shot searches ------------------------------------------------- */
+int smartgpu_search64(int algo, const uint8_t* P, uint32_t m, const smartgpu_text* text,
+                      uint64_t off, uint64_t n, uint64_t* count, double* pre_ms, double* run_ms)
+{
+    const int rc = check_search_args(algo, P, m, text, off, n);
+    if (rc != SMARTGPU_OK) return rc;
+    smartgpu_plan* p = smartgpu_plan_create(algo, P, m, text->device);  // preprocessing phase
+    if (!p) return SMARTGPU_ERR_HIP;
+    uint64_t c = 0;
+    double kms = 0.0;
+    const double t0 = now_ms();
+    int r = smartgpu_plan_launch(p, text, off, n, 0, 1);                 // searching phase
+    if (r == SMARTGPU_OK) r = smartgpu_plan_result(p, 0, &c, &kms);
+    const double wall = now_ms() - t0;
+    g_last_pre_ms = p->pre_ms;
+    g_last_run_ms = wall;  // launch -> count on host, the run_time analogue (main.h:29,31)
+    smartgpu_plan_free(p);
+    if (r != SMARTGPU_OK) return r;
+    if (count) *count = c;
+    if (pre_ms) *pre_ms = g_last_pre_ms;
+    if (run_ms) *run_ms = g_last_run_ms;
+    return SMARTGPU_OK;
+}
+
+void smartgpu_last_times(double* pre_ms, double* run_ms)
+{
+    if (pre_ms) *pre_ms = g_last_pre_ms;
+    if (run_ms) *run_ms = g_last_run_ms;
+}
+
+static int search_host(int algo, const unsigned char* P, int m, const unsigned char* T, int n)
+{
+    if (!P || !T || m < 1 || n < 0) return SMARTGPU_NA;
+    if (m > SMARTGPU_XSIZE) return SMARTGPU_NA;
+    smartgpu_text* t = smartgpu_text_upload(T, static_cast<uint64_t>(n), 0);
+    if (!t) return SMARTGPU_NA;
+    uint64_t c = 0;
+    const int rc = smartgpu_search64(algo, P, static_cast<uint32_t>(m), t, 0, static_cast<uint64_t>(n), &c, nullptr, nullptr);
+    smartgpu_text_free(t);
+    if (rc != SMARTGPU_OK || c > 0x7FFFFFFFull) return SMARTGPU_NA;
+    return static_cast<int>(c);
+}
+
+int smartgpu_hor_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_HOR, P, m, T, n); }
+int smartgpu_bm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_BM, P, m, T, n); }
+int smartgpu_kmp_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_KMP, P, m, T, n); }
+int smartgpu_so_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_SO, P, m, T, n); }
+int smartgpu_bndm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_BNDM, P, m, T, n); }
+int smartgpu_epsm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_EPSM, P, m, T, n); }
+
+/* ---- table export (tests) ---------------------------------------------- */
+int smartgpu_build_table(int which, const uint8_t* P, uint32_t m, int32_t* out, uint32_t cap)
+{
+    if (!P || !out || m < 1 || m > SMARTGPU_XSIZE) { set_error("bad build_table arguments"); return SMARTGPU_ERR_ARG; }
+    std::vector<int32_t> v;
+    switch (which) {
+        case 0: v = sg::bad_char(P, m); break;
+        case 1: v = sg::good_suffix(P, m); break;
+        case 2: v = sg::kmp_next(P, m); break;
+        case 3: { auto s = sg::shift_or_masks(P, m); v.assign(s.begin(), s.end()); break; }
+        case 4: { auto b = sg::bndm_masks(P, m); v.assign(b.begin(), b.end()); break; }
+        default: set_error("unknown table %d", which); return SMARTGPU_ERR_ARG;
+    }
+    if (v.size() > cap) { set_error("table needs %zu entries, cap %u", v.size(), cap); return SMARTGPU_ERR_ARG; }
+    std::memcpy(out, v.data(), v.size() * sizeof(int32_t));
+    return static_cast<int>(v.size());
+}
+
+}  // extern "C"

@@ -1,0 +1,636 @@
+// kernels.hip — gfx950 (CDNA4, wave64) scan kernels for exact string matching.
+//
+// One kernel per SMART algorithm name; all of them compute the same function
+//     count(P,T) = |{ s in [s_begin, s_end) : T[s..s+m) == P }|
+// and differ in the per-lane scan strategy and the tables they stage in LDS.
+//
+// Common structure of the LDS-tiled kernels
+//   * the text is cut into tiles of TB = THREADS*L bytes on ABSOLUTE text
+//     offsets (tile t = bytes [t*TB, (t+1)*TB)), so every tile load is 16-byte
+//     aligned and fully coalesced (global_load_dwordx4, 1 KiB per wave-load);
+//   * a workgroup stages tile + halo into LDS, then each lane owns a contiguous
+//     run of L positions inside the tile and runs the algorithm's own loop
+//     against LDS with the algorithm's own tables (also in LDS);
+//   * restarting the algorithm at a lane/tile/GPU boundary preserves the count
+//     (SURVEY.md §7 restart table): skip algorithms carry no state between
+//     windows, the automata restart in their initial state and re-scan m-1 bytes;
+//   * per-lane hit counters are summed across the 64-lane wave and one 64-bit
+//     atomic per wave goes to the result slot.
+//
+// Skip kernels (HOR, BM, BNDM) index tiles by window END position e = s+m-1 and
+// keep a BACK halo of H = min(m-1, 256) bytes in LDS: the byte that drives the
+// shift, T[e], is always in the tile, verification runs right-to-left through
+// the halo and — only for m-1 > H and only after H+1 bytes matched — continues
+// in global memory.  Serial kernels (SO, KMP) index tiles by START position and
+// keep a forward halo.
+#include "kernels.hpp"
+
+#include "../../include/smartgpu.h"
+
+namespace sg {
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
+
+// Stage nbytes (multiple of 16) from 16-byte-aligned global memory to
+// 16-byte-aligned LDS, 16 B per lane per step (coalesced 1 KiB per wave-load).
+template <int THREADS>
+__device__ __forceinline__ void stage_bytes(uint8_t* __restrict__ lds,
+                                            const uint8_t* __restrict__ src, uint32_t nbytes)
+{
+    for (uint32_t o = threadIdx.x * 16u; o < nbytes; o += THREADS * 16u)
+        *reinterpret_cast<uint4*>(lds + o) = *reinterpret_cast<const uint4*>(src + o);
+}
+
+// Fixed-size variant: TB bytes with all loads issued before the LDS stores.
+template <int THREADS, int TB>
+__device__ __forceinline__ void stage_tile(uint8_t* __restrict__ lds,
+                                           const uint8_t* __restrict__ src)
+{
+    constexpr int N = TB / (THREADS * 16);
+    static_assert(TB % (THREADS * 16) == 0, "tile must be whole 16-byte rows");
+    uint4 v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        v[k] = *reinterpret_cast<const uint4*>(src + (k * THREADS + threadIdx.x) * 16);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        *reinterpret_cast<uint4*>(lds + (k * THREADS + threadIdx.x) * 16) = v[k];
+}
+
+// Sum the per-lane hit counters over the 64-lane wave; one atomic per wave.
+__device__ __forceinline__ void flush_hits(uint32_t lane_hits, unsigned long long* out)
+{
+    unsigned long long v = lane_hits;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(out, v);
+}
+
+__device__ __forceinline__ bool global_equal(const uint8_t* __restrict__ a,
+                                             const uint8_t* __restrict__ b, uint32_t len)
+{
+    uint32_t i = 0;
+    while (i < len && a[i] == b[i]) ++i;
+    return i == len;
+}
+
+// ---------------------------------------------------------------------------
+// Horspool  (reference: src/algos/hor.c:26-51)
+// LDS: u16 tab[256] | pattern tail P[m-1-H..m-1] | text [tile0-H16, tile0+TB)
+// tab[c] = hbc[c] | 0x8000 when c == P[m-1]: the byte that selects the shift
+// also answers the first comparison, so a window costs two LDS reads.
+// ---------------------------------------------------------------------------
+template <int THREADS, int L>
+__global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_first,
+                                                    uint32_t ntiles)
+{
+    constexpr int TB = THREADS * L;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m, H = a.halo, H16 = round16(H);
+    uint16_t* tab = reinterpret_cast<uint16_t*>(smem);
+    uint8_t* ptail = smem + 512;                 // ptail[H-k] == P[m-1-k]
+    uint8_t* txt = ptail + round16(H + 1);       // txt[H16 + x] == T[tile0 + x]
+
+    for (uint32_t i = threadIdx.x; i < 256; i += THREADS)
+        tab[i] = reinterpret_cast<const uint16_t*>(a.blob + kTableOff)[i];
+    for (uint32_t i = threadIdx.x; i <= H; i += THREADS) ptail[i] = a.blob[m - 1 - H + i];
+
+    const uint64_t e_begin = a.s_begin + m - 1, e_end = a.s_end + m - 1;
+    uint32_t hits = 0;
+    for (uint64_t t = tile_first + blockIdx.x; t < tile_first + ntiles; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();  // previous tile fully consumed (and tables visible)
+        stage_bytes<THREADS>(txt, a.text + tile0 - H16, H16);
+        stage_tile<THREADS, TB>(txt + H16, a.text + tile0);
+        __syncthreads();
+        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+        const uint64_t lo = seg > e_begin ? seg : e_begin;
+        const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+        if (lo < hi) {
+            uint32_t e = (uint32_t)(lo - tile0) + H16;
+            const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
+            while (e < ehi) {
+                const uint32_t ent = tab[txt[e]];
+                if (ent & 0x8000u) {
+                    uint32_t k = 1;  // bytes matched so far, right to left
+                    while (k <= H && ptail[H - k] == txt[e - k]) ++k;
+                    bool ok = k > H;
+                    if (ok && m - 1 > H) {
+                        const uint64_t s = tile0 + (e - H16) - (m - 1);
+                        ok = global_equal(a.text + s, a.blob, m - 1 - H);
+                    }
+                    hits += ok;
+                }
+                e += ent & 0x7FFFu;
+            }
+        }
+    }
+    flush_hits(hits, a.count);
+}
+
+// ---------------------------------------------------------------------------
+// Boyer-Moore  (reference: src/algos/bm.c:27-93)
+// LDS: u16 bc[256] | u16 gs[m] | pattern tail | text [tile0-H16, tile0+TB)
+// ---------------------------------------------------------------------------
+template <int THREADS, int L>
+__global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_first,
+                                                   uint32_t ntiles)
+{
+    constexpr int TB = THREADS * L;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m, H = a.halo, H16 = round16(H);
+    uint16_t* bc = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* gs = bc + 256;
+    uint8_t* ptail = smem + 512 + round16(2 * m);
+    uint8_t* txt = ptail + round16(H + 1);
+
+    const uint16_t* gtab = reinterpret_cast<const uint16_t*>(a.blob + kTableOff);
+    for (uint32_t i = threadIdx.x; i < 256 + m; i += THREADS) bc[i] = gtab[i];
+    for (uint32_t i = threadIdx.x; i <= H; i += THREADS) ptail[i] = a.blob[m - 1 - H + i];
+
+    const uint64_t e_begin = a.s_begin + m - 1, e_end = a.s_end + m - 1;
+    uint32_t hits = 0;
+    for (uint64_t t = tile_first + blockIdx.x; t < tile_first + ntiles; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();
+        stage_bytes<THREADS>(txt, a.text + tile0 - H16, H16);
+        stage_tile<THREADS, TB>(txt + H16, a.text + tile0);
+        __syncthreads();
+        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+        const uint64_t lo = seg > e_begin ? seg : e_begin;
+        const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+        if (lo < hi) {
+            uint32_t e = (uint32_t)(lo - tile0) + H16;
+            const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
+            while (e < ehi) {
+                // right-to-left comparison (bm.c:83); k = bytes matched
+                uint32_t k = 0, c = 0;
+                bool mismatch = false;
+                while (k <= H) {
+                    c = txt[e - k];
+                    if (c != ptail[H - k]) { mismatch = true; break; }
+                    ++k;
+                }
+                if (!mismatch && k < m) {  // the halo is exhausted: go on in HBM
+                    const uint8_t* tp = a.text + tile0 + (e - H16);
+                    while (k < m) {
+                        c = tp[-(int64_t)k];
+                        if (c != a.blob[m - 1 - k]) { mismatch = true; break; }
+                        ++k;
+                    }
+                }
+                uint32_t shift;
+                if (!mismatch) {
+                    ++hits;
+                    shift = gs[0];  // bm.c:86
+                } else {
+                    const int g = gs[m - 1 - k];
+                    const int b = (int)bc[c] - (int)k;  // bmBc[c] - m + 1 + i, i = m-1-k
+                    shift = (uint32_t)(g > b ? g : b);  // bm.c:89
+                }
+                e += shift;
+            }
+        }
+    }
+    flush_hits(hits, a.count);
+}
+
+// ---------------------------------------------------------------------------
+// BNDM, 32-bit words like the reference  (src/algos/bndm.c:27-111)
+// w = min(m,32); tiles are indexed by the END of the w-byte (prefix) window.
+// LDS: u32 B[256] | text [tile0-32, tile0+TB)
+// ---------------------------------------------------------------------------
+template <int THREADS, int L>
+__global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_first,
+                                                     uint32_t ntiles)
+{
+    constexpr int TB = THREADS * L;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m, w = m < 32 ? m : 32, H16 = 32;
+    uint32_t* B = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* txt = smem + 1024;
+
+    for (uint32_t i = threadIdx.x; i < 256; i += THREADS)
+        B[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i];
+
+    const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
+    uint32_t hits = 0;
+    for (uint64_t t = tile_first + blockIdx.x; t < tile_first + ntiles; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();
+        stage_bytes<THREADS>(txt, a.text + tile0 - H16, H16);
+        stage_tile<THREADS, TB>(txt + H16, a.text + tile0);
+        __syncthreads();
+        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+        const uint64_t lo = seg > e_begin ? seg : e_begin;
+        const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+        if (lo < hi) {
+            uint32_t e = (uint32_t)(lo - tile0) + H16;
+            const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
+            while (e < ehi) {
+                int i = (int)w - 1;
+                uint32_t last = w, D = 0xFFFFFFFFu, k = 0;
+                while (i >= 0 && D != 0) {  // bndm.c:49-58
+                    D &= B[txt[e - k]];
+                    ++k;
+                    --i;
+                    if (D != 0) {
+                        if (i >= 0) {
+                            last = (uint32_t)i + 1;
+                        } else if (w == m) {
+                            ++hits;
+                        } else {
+                            // prefix of 32 matched: verify P[32..m) (bndm.c:99-102),
+                            // the window is inside the text because s < s_end
+                            const uint64_t s = tile0 + (e - H16) - (w - 1);
+                            hits += global_equal(a.text + s + w, a.blob + w, m - w);
+                        }
+                    }
+                    D <<= 1;
+                }
+                e += last;
+            }
+        }
+    }
+    flush_hits(hits, a.count);
+}
+
+// ---------------------------------------------------------------------------
+// Shift-Or, 32-bit words like the reference  (src/algos/so.c:27-96)
+// Tiles indexed by START position; lane scans bytes [a, b+w-1) with D = ~0 at a.
+// L/16 is odd so the lanes' 16-byte LDS reads fall in distinct bank groups.
+// LDS: u32 S[256] | text [tile0, tile0+TB+32)
+// ---------------------------------------------------------------------------
+template <int THREADS, int L>
+__global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a, uint64_t tile_first,
+                                                   uint32_t ntiles)
+{
+    constexpr int TB = THREADS * L;
+    static_assert((L / 16) % 2 == 1, "L/16 must be odd (LDS bank spread)");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m, w = m < 32 ? m : 32;
+    const uint32_t hibit = 1u << (w - 1);
+    uint32_t* S = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* txt = smem + 1024;
+
+    for (uint32_t i = threadIdx.x; i < 256; i += THREADS)
+        S[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i];
+
+    uint32_t hits = 0;
+    for (uint64_t t = tile_first + blockIdx.x; t < tile_first + ntiles; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();
+        stage_tile<THREADS, TB>(txt, a.text + tile0);
+        stage_bytes<THREADS>(txt + TB, a.text + tile0 + TB, 32);
+        __syncthreads();
+        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
+        const uint64_t sb = seg + L < a.s_end ? seg + L : a.s_end;
+        if (sa < sb) {
+            const uint32_t j0 = (uint32_t)(sa - tile0);
+            const uint32_t jend = (uint32_t)(sb - tile0) + w - 1;
+            uint32_t D = 0xFFFFFFFFu;
+            for (uint32_t base = j0 & ~15u; base < jend; base += 16) {
+                const uint4 v = *reinterpret_cast<const uint4*>(txt + base);
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t j = base + q;
+                    const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+                    const bool live = (j >= j0) & (j < jend);
+                    if (live) {
+                        D = (D << 1) | S[c];  // so.c:55
+                        if (!(D & hibit)) {   // so.c:56  (D < lim)
+                            if (w == m) {
+                                ++hits;
+                            } else {
+                                const uint64_t h = tile0 + j - (w - 1);
+                                hits += global_equal(a.text + h + w, a.blob + w, m - w);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    flush_hits(hits, a.count);
+}
+
+// ---------------------------------------------------------------------------
+// Knuth-Morris-Pratt  (reference: src/algos/kmp.c:27-68)
+// Lane restarts in state 0 at its first start position and scans m-1 bytes
+// into the next lane's run.  LDS: pattern | i16 next[m+1] | text [tile0, tile0+TB+halo)
+// ---------------------------------------------------------------------------
+template <int THREADS, int L>
+__global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a, uint64_t tile_first,
+                                                    uint32_t ntiles)
+{
+    constexpr int TB = THREADS * L;
+    static_assert((L / 16) % 2 == 1, "L/16 must be odd (LDS bank spread)");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int m = (int)a.m;
+    const uint32_t FH16 = round16(a.halo);  // forward halo, a.halo = m-1
+    uint8_t* pat = smem;
+    int16_t* next = reinterpret_cast<int16_t*>(smem + round16(m));
+    uint8_t* txt = smem + round16(m) + round16(2 * (m + 1));
+
+    for (uint32_t i = threadIdx.x; i < (uint32_t)m; i += THREADS) pat[i] = a.blob[i];
+    for (uint32_t i = threadIdx.x; i <= (uint32_t)m; i += THREADS)
+        next[i] = reinterpret_cast<const int16_t*>(a.blob + kTableOff)[i];
+    const uint32_t p0 = a.blob[0];
+
+    uint32_t hits = 0;
+    for (uint64_t t = tile_first + blockIdx.x; t < tile_first + ntiles; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();
+        stage_tile<THREADS, TB>(txt, a.text + tile0);
+        stage_bytes<THREADS>(txt + TB, a.text + tile0 + TB, FH16);
+        __syncthreads();
+        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
+        const uint64_t sb = seg + L < a.s_end ? seg + L : a.s_end;
+        if (sa < sb) {
+            const uint32_t j0 = (uint32_t)(sa - tile0);
+            const uint32_t jend = (uint32_t)(sb - tile0) + (uint32_t)m - 1;
+            int st = 0;  // pattern bytes matched so far (kmp.c: i)
+            for (uint32_t base = j0 & ~15u; base < jend; base += 16) {
+                const uint4 v = *reinterpret_cast<const uint4*>(txt + base);
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t j = base + q;
+                    const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+                    const bool live = (j >= j0) & (j < jend);
+                    if (live) {
+                        if (st == 0) {
+                            st = (c == p0) ? 1 : 0;  // next[0] = -1, then ++ (kmp.c:57-60)
+                        } else {
+                            while (st >= 0 && pat[st] != c) st = next[st];
+                            ++st;
+                        }
+                        if (st >= m) {  // kmp.c:61-64
+                            ++hits;
+                            st = next[m];
+                        }
+                    }
+                }
+            }
+        }
+    }
+    flush_hits(hits, a.count);
+}
+
+// ---------------------------------------------------------------------------
+// EPSM — packed matching  (reference: src/algos/epsm.c; the SSE regimes map to
+// one VALU scheme here).  Each lane takes 16 consecutive start positions per
+// step straight from registers: 32 text bytes (its own 16 and the next 16) give
+// every unaligned dword via v_alignbyte_b32; the first F = min(m,16) pattern
+// bytes are compared as up to four masked dwords at all 16 alignments, later
+// dwords only when some lane of the wave still has a candidate; m > 16 verifies
+// the rest from memory.  No LDS, no tables beyond the 4-dword fingerprint.
+// Matches are reduced with popcount over the per-lane candidate masks.
+// ---------------------------------------------------------------------------
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void epsm_scan(ScanArgs a, uint64_t row_first,
+                                                     uint64_t nrows)
+{
+    const uint32_t m = a.m;
+    const uint32_t* fpw = reinterpret_cast<const uint32_t*>(a.blob + kTableOff);
+    const uint32_t f0 = fpw[0], f1 = fpw[1], f2 = fpw[2], f3 = fpw[3];
+    const uint32_t k0 = fpw[4], k1 = fpw[5], k2 = fpw[6], k3 = fpw[7];
+    const uint32_t nd = (m >= 13) ? 4 : (m + 3) / 4;  // fingerprint dwords
+
+    uint32_t hits = 0;
+    // a "row" is THREADS*16 consecutive absolute text offsets
+    for (uint64_t r = row_first + blockIdx.x; r < row_first + nrows; r += gridDim.x) {
+        const uint64_t p0 = (r * THREADS + threadIdx.x) * 16;
+        const uint4 A = *reinterpret_cast<const uint4*>(a.text + p0);
+        const uint4 Bv = *reinterpret_cast<const uint4*>(a.text + p0 + 16);
+        const uint32_t d[8] = {A.x, A.y, A.z, A.w, Bv.x, Bv.y, Bv.z, Bv.w};
+        // positions p0+k inside [s_begin, s_end)
+        const uint64_t lo64 = a.s_begin > p0 ? a.s_begin - p0 : 0;
+        const uint64_t hi64 = a.s_end > p0 ? a.s_end - p0 : 0;
+        const uint32_t lo = lo64 > 16 ? 16u : (uint32_t)lo64;
+        const uint32_t hi = hi64 > 16 ? 16u : (uint32_t)hi64;
+        uint32_t cand = (hi > lo) ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+
+        // w(x) = text dword at byte offset x of the 32-byte window
+#define SG_W(x) (((x) & 3) == 0 ? d[(x) >> 2] \
+                                : __builtin_amdgcn_alignbyte(d[((x) >> 2) + 1], d[(x) >> 2], (x) & 3))
+        {
+            uint32_t eq = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) eq |= ((SG_W(k) & k0) == f0) ? (1u << k) : 0u;
+            cand &= eq;
+        }
+        if (nd > 1 && __any(cand != 0)) {
+            uint32_t eq = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) eq |= ((SG_W(k + 4) & k1) == f1) ? (1u << k) : 0u;
+            cand &= eq;
+            if (nd > 2 && __any(cand != 0)) {
+                eq = 0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) eq |= ((SG_W(k + 8) & k2) == f2) ? (1u << k) : 0u;
+                cand &= eq;
+                if (nd > 3) {
+                    eq = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        eq |= ((SG_W(k + 12) & k3) == f3) ? (1u << k) : 0u;
+                    cand &= eq;
+                }
+            }
+        }
+#undef SG_W
+        if (m > 16) {
+            uint32_t c = cand;
+            while (c) {
+                const uint32_t k = __builtin_ctz(c);
+                c &= c - 1;
+                if (!global_equal(a.text + p0 + k + 16, a.blob + 16, m - 16)) cand &= ~(1u << k);
+            }
+        }
+        hits += __popc(cand);
+    }
+    flush_hits(hits, a.count);
+}
+
+// ---------------------------------------------------------------------------
+// corpus kernels
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// dst[i] = corpus byte (off+i); one thread produces one aligned 8-byte corpus word
+// (one 8-byte store when the word lies wholly inside the request and off%8==0).
+__global__ __launch_bounds__(256) void generate_text(uint8_t* dst, uint64_t seed, uint32_t sigma,
+                                                     uint64_t off, uint64_t n)
+{
+    const uint64_t w_first = off >> 3, w_last = (off + n + 7) >> 3;  // corpus words touched
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const bool pow2 = (sigma & (sigma - 1)) == 0;
+    const bool aligned = (off & 7) == 0;
+    for (uint64_t wi = w_first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < w_last;
+         wi += stride) {
+        const uint64_t x = splitmix64(seed + wi);
+        uint64_t y;
+        if (pow2) {
+            y = x & (0x0101010101010101ull * (uint64_t)(sigma - 1));
+        } else {
+            y = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                y |= (uint64_t)(((uint32_t)(x >> (8 * b)) & 0xFFu) % sigma) << (8 * b);
+        }
+        const uint64_t j0 = wi << 3;  // corpus offset of byte 0 of this word
+        if (aligned && j0 + 8 <= off + n) {
+            *reinterpret_cast<uint64_t*>(dst + (j0 - off)) = y;
+        } else {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint64_t j = j0 + b;
+                if (j >= off && j < off + n) dst[j - off] = (uint8_t)(y >> (8 * b));
+            }
+        }
+    }
+}
+
+// dst[i] = unit[(phase + i) % unit_len]
+__global__ __launch_bounds__(256) void tile_fill(uint8_t* dst, const uint8_t* unit,
+                                                 uint64_t unit_len, uint64_t phase, uint64_t n)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        dst[i] = unit[(phase + i) % unit_len];
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+namespace {
+
+struct TileRange { uint64_t first; uint32_t count; };
+
+// tiles of `tb` absolute offsets intersecting [lo, hi)
+TileRange tiles_for(uint64_t lo, uint64_t hi, uint64_t tb)
+{
+    if (hi <= lo) return {0, 0};
+    const uint64_t first = lo / tb, last = (hi - 1) / tb;
+    return {first, (uint32_t)(last - first + 1)};
+}
+
+uint32_t r16(uint32_t x) { return (x + 15u) & ~15u; }
+
+template <typename K>
+hipError_t launch_tiled(K kernel, const ScanArgs& a, TileRange tr, int threads, size_t lds,
+                        int wgs_per_cu, int num_cus, hipStream_t stream)
+{
+    if (tr.count == 0) return hipSuccess;
+    uint32_t grid = (uint32_t)num_cus * (uint32_t)wgs_per_cu;
+    if (grid > tr.count) grid = tr.count;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a, tr.first, tr.count);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// tile shapes (threads, bytes per lane)
+constexpr int kHorT = 256, kHorL = 64;
+constexpr int kBmT = 256, kBmL = 64;
+constexpr int kBndmT = 256, kBndmL = 64;
+constexpr int kSoT = 256, kSoL = 80;
+constexpr int kKmpT = 128, kKmpL = 272;
+constexpr int kEpsmT = 256;
+
+const char* scan_kernel_name(int algo, uint32_t)
+{
+    switch (algo) {
+        case SMARTGPU_HOR: return "hor_scan";
+        case SMARTGPU_BM: return "bm_scan";
+        case SMARTGPU_KMP: return "kmp_scan";
+        case SMARTGPU_SO: return "so_scan";
+        case SMARTGPU_BNDM: return "bndm_scan";
+        case SMARTGPU_EPSM: return "epsm_scan";
+    }
+    return "?";
+}
+
+hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream)
+{
+    if (a.s_end <= a.s_begin) return hipSuccess;
+    const uint32_t m = a.m;
+    switch (algo) {
+        case SMARTGPU_HOR: {
+            const uint32_t H = a.halo;
+            const size_t lds = 512 + r16(H + 1) + r16(H) + (size_t)kHorT * kHorL;
+            const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
+            return launch_tiled(hor_scan<kHorT, kHorL>, a, tr, kHorT, lds, 8, num_cus, stream);
+        }
+        case SMARTGPU_BM: {
+            const uint32_t H = a.halo;
+            const size_t lds = 512 + r16(2 * m) + r16(H + 1) + r16(H) + (size_t)kBmT * kBmL;
+            const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmT * kBmL);
+            return launch_tiled(bm_scan<kBmT, kBmL>, a, tr, kBmT, lds, 6, num_cus, stream);
+        }
+        case SMARTGPU_BNDM: {
+            const uint32_t w = m < 32 ? m : 32;
+            const size_t lds = 1024 + 32 + (size_t)kBndmT * kBndmL;
+            const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
+            return launch_tiled(bndm_scan<kBndmT, kBndmL>, a, tr, kBndmT, lds, 8, num_cus, stream);
+        }
+        case SMARTGPU_SO: {
+            const size_t lds = 1024 + (size_t)kSoT * kSoL + 32;
+            const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kSoT * kSoL);
+            return launch_tiled(so_scan<kSoT, kSoL>, a, tr, kSoT, lds, 6, num_cus, stream);
+        }
+        case SMARTGPU_KMP: {
+            const size_t lds = r16(m) + r16(2 * (m + 1)) + (size_t)kKmpT * kKmpL + r16(m - 1);
+            const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kKmpT * kKmpL);
+            return launch_tiled(kmp_scan<kKmpT, kKmpL>, a, tr, kKmpT, lds, 3, num_cus, stream);
+        }
+        case SMARTGPU_EPSM: {
+            const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kEpsmT * 16);
+            if (tr.count == 0) return hipSuccess;
+            uint64_t grid = (uint64_t)num_cus * 8;
+            if (grid > tr.count) grid = tr.count;
+            hipLaunchKernelGGL(epsm_scan<kEpsmT>, dim3((uint32_t)grid), dim3(kEpsmT), 0, stream, a,
+                               tr.first, (uint64_t)tr.count);
+            return hipGetLastError();
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_generate(uint8_t* dst, uint64_t seed, int sigma, uint64_t off, uint64_t n,
+                           hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t words = ((off + n + 7) >> 3) - (off >> 3);
+    uint64_t grid = (words + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(generate_text, dim3((uint32_t)grid), dim3(256), 0, stream, dst, seed,
+                       (uint32_t)sigma, off, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_fill(uint8_t* dst, const uint8_t* unit, uint64_t unit_len, uint64_t phase,
+                            uint64_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t grid = (n + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(tile_fill, dim3((uint32_t)grid), dim3(256), 0, stream, dst, unit, unit_len,
+                       phase, n);
+    return hipGetLastError();
+}
+
+}  // namespace sg

@@ -1,0 +1,55 @@
+// kernels.hpp — launch interface between the C-ABI layer (api.cpp) and the
+// gfx950 scan kernels (kernels.hip).  Host-only types; no HIP headers needed
+// by includers other than hipStream_t.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sg {
+
+// ---- text buffer geometry (HBM layout) --------------------------------------
+// A text of n bytes lives in one allocation  [FRONT_PAD | n bytes | back pad],
+// pads zero-filled.  Text byte 0 is 256-byte aligned.  The pads let every tile
+// load (a tile plus its halo, rounded to 16 B) stay inside the allocation with
+// no per-load bounds checks; pad bytes are never counted as text.
+constexpr uint64_t kFrontPad = 4608;            // >= kXSize + 256, multiple of 256
+constexpr uint64_t kBackPad = 160 * 1024;       // >= largest tile + kXSize + 64
+constexpr uint32_t kHaloMax = 256;              // back-halo bytes kept in LDS by the skip kernels
+constexpr uint32_t kPatternBytes = 4224;        // pattern slot in the plan blob (>= kXSize, /16)
+constexpr int kResultSlots = 4096;
+
+// What every scan kernel receives.
+struct ScanArgs {
+    const uint8_t* text;        // device pointer to text byte 0
+    uint64_t s_begin, s_end;    // start positions to count: s_begin <= s < s_end (s_end <= n-m+1)
+    uint32_t m;                 // pattern length
+    uint32_t halo;              // skip kernels: back-halo H = min(m-1, kHaloMax); serial: forward halo
+    const uint8_t* blob;        // device: [pattern kPatternBytes][tables ...]
+    unsigned long long* count;  // device result slot (pre-zeroed)
+};
+
+// Byte offsets of the tables inside the blob, after the pattern slot.
+//  HOR : u16 tab[256]   shift | 0x8000 if c == P[m-1]
+//  BM  : u16 bc[256], u16 gs[m]
+//  KMP : i16 next[m+1]
+//  SO  : u32 S[256]
+//  BNDM: u32 B[256]
+//  EPSM: u32 fp[4], u32 fpmask[4]   (first min(m,16) pattern bytes as dwords + byte masks)
+constexpr uint32_t kTableOff = kPatternBytes;
+
+struct LaunchInfo {
+    const char* kernel_name;  // as rocprofv3 prints it
+};
+
+// Enqueue the scan for `algo` on `stream`; returns hipSuccess or the launch error.
+hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream);
+const char* scan_kernel_name(int algo, uint32_t m);
+
+// text generators / helpers (device side)
+hipError_t launch_generate(uint8_t* dst, uint64_t seed, int sigma, uint64_t off, uint64_t n,
+                           hipStream_t stream);
+hipError_t launch_tile_fill(uint8_t* dst, const uint8_t* unit, uint64_t unit_len, uint64_t phase,
+                            uint64_t n, hipStream_t stream);
+
+}  // namespace sg

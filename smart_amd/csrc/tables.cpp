@@ -1,0 +1,91 @@
+// tables.cpp — host-side preprocessing for the scan kernels.  See tables.hpp.
+#include "tables.hpp"
+
+#include <algorithm>
+
+namespace sg {
+
+std::vector<int32_t> bad_char(const uint8_t* P, uint32_t m)
+{
+    std::vector<int32_t> shift(kSigma, static_cast<int32_t>(m));
+    for (uint32_t i = 0; i + 1 < m; ++i) shift[P[i]] = static_cast<int32_t>(m - 1 - i);
+    return shift;
+}
+
+// suff[i] = |longest common suffix of P[0..i] and P|.  Computed as the
+// Z-array of the reversed pattern: suff[i] = Z[m-1-i].
+static std::vector<int32_t> suffix_lengths(const uint8_t* P, uint32_t m)
+{
+    const int32_t M = static_cast<int32_t>(m);
+    std::vector<uint8_t> r(P, P + m);
+    std::reverse(r.begin(), r.end());
+    std::vector<int32_t> z(m, 0);
+    z[0] = M;
+    int32_t lo = 0, hi = 0;  // [lo,hi) = right-most Z-box
+    for (int32_t i = 1; i < M; ++i) {
+        int32_t k = 0;
+        if (i < hi) k = std::min(z[i - lo], hi - i);
+        while (i + k < M && r[k] == r[i + k]) ++k;
+        z[i] = k;
+        if (i + k > hi) { lo = i; hi = i + k; }
+    }
+    std::vector<int32_t> suff(m);
+    for (int32_t i = 0; i < M; ++i) suff[i] = z[M - 1 - i];
+    return suff;
+}
+
+std::vector<int32_t> good_suffix(const uint8_t* P, uint32_t m)
+{
+    const int32_t M = static_cast<int32_t>(m);
+    const std::vector<int32_t> suff = suffix_lengths(P, m);
+    std::vector<int32_t> gs(m, M);
+    // a border of P (prefix == suffix of length i+1) bounds the shift for every
+    // mismatch position left of it
+    int32_t j = 0;
+    for (int32_t i = M - 1; i >= 0; --i) {
+        if (suff[i] != i + 1) continue;
+        for (; j < M - 1 - i; ++j)
+            if (gs[j] == M) gs[j] = M - 1 - i;
+    }
+    // an inner re-occurrence of the matched suffix
+    for (int32_t i = 0; i <= M - 2; ++i) gs[M - 1 - suff[i]] = M - 1 - i;
+    return gs;
+}
+
+std::vector<int32_t> kmp_next(const uint8_t* P, uint32_t m)
+{
+    // border[i] = length of the longest proper border of P[0..i)
+    std::vector<int32_t> border(m + 1, 0);
+    border[0] = -1;
+    int32_t b = -1;
+    for (uint32_t i = 0; i < m; ++i) {
+        while (b >= 0 && P[i] != P[b]) b = border[b];
+        border[i + 1] = ++b;
+    }
+    // strong links: never fall back to a state that fails on the same byte
+    std::vector<int32_t> next(m + 1);
+    next[0] = -1;
+    for (uint32_t i = 1; i <= m; ++i) {
+        const int32_t bi = border[i];
+        next[i] = (i < m && P[i] == P[bi]) ? next[bi] : bi;
+    }
+    return next;
+}
+
+std::vector<uint32_t> shift_or_masks(const uint8_t* P, uint32_t m)
+{
+    const uint32_t w = std::min<uint32_t>(m, 32);
+    std::vector<uint32_t> S(kSigma, 0xFFFFFFFFu);
+    for (uint32_t i = 0; i < w; ++i) S[P[i]] &= ~(1u << i);
+    return S;
+}
+
+std::vector<uint32_t> bndm_masks(const uint8_t* P, uint32_t m)
+{
+    const uint32_t w = std::min<uint32_t>(m, 32);
+    std::vector<uint32_t> B(kSigma, 0u);
+    for (uint32_t i = 0; i < w; ++i) B[P[i]] |= 1u << (w - 1 - i);
+    return B;
+}
+
+}  // namespace sg

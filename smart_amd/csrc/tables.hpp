@@ -1,0 +1,33 @@
+// tables.hpp — host-side preprocessing for the scan kernels (plain C++).
+//
+// Each builder produces the table of the cited SMART algorithm; the kernels
+// stage these tables in LDS.  Layouts are the device layouts (narrow integer
+// types, flags folded in) — `*_ref32` variants give the reference's int layout
+// for the table-parity tests (smartgpu_build_table).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace sg {
+
+constexpr uint32_t kSigma = 256;   // src/algos/include/define.h:27
+constexpr uint32_t kXSize = 4200;  // src/algos/include/define.h:25
+
+// Horspool / BM bad-character shifts (hor.c:26-30, bm.c:27-33): for every byte c
+// the distance from its right-most occurrence in P[0..m-2] to P[m-1], m if none.
+std::vector<int32_t> bad_char(const uint8_t* P, uint32_t m);
+
+// BM good-suffix shifts (bm.c:36-66) via the suffix-length array.
+std::vector<int32_t> good_suffix(const uint8_t* P, uint32_t m);
+
+// KMP strong failure links next[0..m] (kmp.c:27-41), next[0] = -1.
+std::vector<int32_t> kmp_next(const uint8_t* P, uint32_t m);
+
+// Shift-Or: S[c] has bit i clear iff P[i]==c, over the first w=min(m,32) bytes
+// (so.c:27-38,73-74).  The hit test "D < lim" (so.c:56) is "bit w-1 of D is 0".
+std::vector<uint32_t> shift_or_masks(const uint8_t* P, uint32_t m);
+
+// BNDM: B[c] has bit (w-1-i) set iff P[i]==c, w=min(m,32) (bndm.c:35-40,74-75).
+std::vector<uint32_t> bndm_masks(const uint8_t* P, uint32_t m);
+
+}  // namespace sg

@@ -1,0 +1,224 @@
+"""ctypes binding of libsmartgpu.so (include/smartgpu.h).
+
+Mirrors SMART's plugin surface: a *text* loaded once (smart.c:553-568,95-138),
+*patterns* cut from it (smart.c:148-158), and per-algorithm `search` calls that
+return an occurrence count plus preprocessing / searching times in ms
+(main.h:28-39).  There is no CPU fallback here: if the HIP library cannot be
+loaded or no device is present, calls raise SmartGpuError.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsmartgpu.so")
+ALGOS = ("hor", "bm", "kmp", "so", "bndm", "epsm")
+
+_lib = None
+
+
+class SmartGpuError(RuntimeError):
+    pass
+
+
+def build():
+    """Compile libsmartgpu.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmartGpuError("%s is missing: run `make -C smart_amd/csrc` (or __graft_entry__.build())" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    sig = {
+        "smartgpu_version": (C.c_char_p, []),
+        "smartgpu_last_error": (C.c_char_p, []),
+        "smartgpu_device_count": (i32, []),
+        "smartgpu_algo_id": (i32, [C.c_char_p]),
+        "smartgpu_algo_name": (C.c_char_p, [i32]),
+        "smartgpu_device_sync": (i32, [i32]),
+        "smartgpu_text_upload": (vp, [vp, u64, i32]),
+        "smartgpu_text_upload_tiled": (vp, [vp, u64, u64, u64, i32]),
+        "smartgpu_text_generate": (vp, [u64, i32, u64, u64, i32]),
+        "smartgpu_text_free": (None, [vp]),
+        "smartgpu_text_length": (u64, [vp]),
+        "smartgpu_text_device": (i32, [vp]),
+        "smartgpu_text_read": (i32, [vp, u64, u64, vp]),
+        "smartgpu_search64": (i32, [i32, vp, u32, vp, u64, u64, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "smartgpu_last_times": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "smartgpu_plan_create": (vp, [i32, vp, u32, i32]),
+        "smartgpu_plan_free": (None, [vp]),
+        "smartgpu_plan_launch": (i32, [vp, vp, u64, u64, i32, i32]),
+        "smartgpu_plan_result": (i32, [vp, i32, C.POINTER(u64), C.POINTER(C.c_double)]),
+        "smartgpu_plan_kernel_name": (C.c_char_p, [vp]),
+        "smartgpu_plan_result_device_ptr": (vp, [vp]),
+        "smartgpu_build_table": (i32, [i32, vp, u32, vp, u32]),
+    }
+    for a in ALGOS:
+        sig["smartgpu_%s_search" % a] = (i32, [vp, i32, vp, i32])
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTS = None  # filled by tests from include/smartgpu.h
+
+
+def _err(what):
+    return SmartGpuError("%s: %s" % (what, lib().smartgpu_last_error().decode()))
+
+
+def version():
+    return lib().smartgpu_version().decode()
+
+
+def device_count():
+    return lib().smartgpu_device_count()
+
+
+def algo_id(name):
+    i = lib().smartgpu_algo_id(name.encode())
+    if i < 0:
+        raise SmartGpuError("unknown algorithm %r" % name)
+    return i
+
+
+def _u8(a):
+    if isinstance(a, (bytes, bytearray)):
+        a = np.frombuffer(bytes(a), dtype=np.uint8)
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class Text:
+    """A text resident in one GPU's HBM (the shmget/getText replacement)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise _err("text")
+        self._h = handle
+
+    @classmethod
+    def upload(cls, data, device=0):
+        data = _u8(data)
+        return cls(lib().smartgpu_text_upload(data.ctypes.data, len(data), device))
+
+    @classmethod
+    def upload_tiled(cls, unit, n, phase=0, device=0):
+        unit = _u8(unit)
+        return cls(lib().smartgpu_text_upload_tiled(unit.ctypes.data, len(unit), phase, n, device))
+
+    @classmethod
+    def generate(cls, seed, sigma, n, off=0, device=0):
+        return cls(lib().smartgpu_text_generate(seed, sigma, off, n, device))
+
+    def __len__(self):
+        return int(lib().smartgpu_text_length(self._h))
+
+    @property
+    def device(self):
+        return lib().smartgpu_text_device(self._h)
+
+    def read(self, off, length):
+        out = np.empty(length, dtype=np.uint8)
+        if lib().smartgpu_text_read(self._h, off, length, out.ctypes.data) != 0:
+            raise _err("text_read")
+        return out
+
+    def pattern(self, k, m):
+        """P = T[k..k+m), as setOfRandomPatterns cuts it (smart.c:148-158)."""
+        return self.read(k, m)
+
+    def free(self):
+        if self._h:
+            lib().smartgpu_text_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Plan:
+    """One (algorithm, pattern) preprocessed and resident on a device."""
+
+    def __init__(self, algo, P, device=0):
+        self.P = _u8(P)
+        self.algo = algo
+        self._h = lib().smartgpu_plan_create(algo_id(algo), self.P.ctypes.data, len(self.P), device)
+        if not self._h:
+            raise _err("plan_create")
+
+    def launch(self, text, slot=0, timed=False, off=0, n=None):
+        if n is None:
+            n = len(text) - off
+        if lib().smartgpu_plan_launch(self._h, text._h, off, n, slot, 1 if timed else 0) != 0:
+            raise _err("plan_launch")
+
+    def result(self, slot=0):
+        c = C.c_uint64(0)
+        ms = C.c_double(0.0)
+        if lib().smartgpu_plan_result(self._h, slot, C.byref(c), C.byref(ms)) != 0:
+            raise _err("plan_result")
+        return int(c.value), float(ms.value)
+
+    @property
+    def kernel_name(self):
+        return lib().smartgpu_plan_kernel_name(self._h).decode()
+
+    @property
+    def result_device_ptr(self):
+        return lib().smartgpu_plan_result_device_ptr(self._h)
+
+    def free(self):
+        if self._h:
+            lib().smartgpu_plan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def search(algo, P, text, off=0, n=None):
+    """(count, pre_ms, run_ms) of `algo` for P in text[off..off+n)."""
+    P = _u8(P)
+    if n is None:
+        n = len(text) - off
+    c = C.c_uint64(0)
+    pre = C.c_double(0.0)
+    run = C.c_double(0.0)
+    rc = lib().smartgpu_search64(algo_id(algo), P.ctypes.data, len(P), text._h, off, n,
+                                 C.byref(c), C.byref(pre), C.byref(run))
+    if rc != 0:
+        raise _err("search64(%s) rc=%d" % (algo, rc))
+    return int(c.value), float(pre.value), float(run.value)
+
+
+def search_host(algo, P, T):
+    """SMART's own `int search(P, m, T, n)` shape on host buffers."""
+    P = _u8(P)
+    T = _u8(T)
+    return getattr(lib(), "smartgpu_%s_search" % algo)(P.ctypes.data, len(P), T.ctypes.data, len(T))
+
+
+def build_table(which, P):
+    P = _u8(P)
+    names = {"bad_char": 0, "good_suffix": 1, "kmp_next": 2, "shift_or": 3, "bndm": 4}
+    out = np.empty(max(256, len(P) + 1), dtype=np.int32)
+    k = lib().smartgpu_build_table(names[which], P.ctypes.data, len(P), out.ctypes.data, len(out))
+    if k < 0:
+        raise _err("build_table")
+    return out[:k].copy()

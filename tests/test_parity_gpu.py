@@ -1,0 +1,202 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI, against the
+oracle and the golden vectors.  Bit-exact (integer counts)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, fuzz_case, load_golden
+
+pytestmark = pytest.mark.gpu
+
+import smart_amd  # noqa: E402
+from smart_amd import Plan, Text  # noqa: E402
+
+ALGOS = smart_amd.ALGOS
+SEED2 = 0x5EED0001  # BASELINE config 2 corpus seed
+
+
+@pytest.fixture(scope="module", autouse=True)
+def need_gpu():
+    assert smart_amd.device_count() > 0, "no HIP device: " + smart_amd.lib().smartgpu_last_error().decode()
+
+
+def gpu_counts(P, text, algos=ALGOS, **kw):
+    return {a: smart_amd.search(a, P, text, **kw)[0] for a in algos}
+
+
+def test_testc_cases():
+    """src/test.c:252-382 through the reference's own `int search(P,m,T,n)` shape."""
+    for r in load_golden("testc_cases.json")["rows"]:
+        P, T = r["P"].encode(), r["T"].encode()
+        for a in ALGOS:
+            assert smart_amd.search_host(a, P, T) == r["count"], (a, r)
+
+
+def test_fuzz_vectors(oracle):
+    rows = load_golden("fuzz_vectors.json")["rows"]
+    for r in rows:
+        P, T = fuzz_case(oracle, r)
+        text = Text.upload(T)
+        got = gpu_counts(P, text)
+        text.free()
+        for a in ALGOS:
+            assert got[a] == r["count"], (a, r, got)
+
+
+def test_survey_vectors(oracle):
+    g = load_golden("survey_vectors.json")
+    texts = {}
+    for r in g["rows"]:
+        if r["sigma"] not in texts:
+            texts[r["sigma"]] = (Text.upload(oracle.textgen(r["sigma"], r["n"])),)
+        text = texts[r["sigma"]][0]
+        P = text.pattern(r["k"], r["m"])
+        got = gpu_counts(P, text)
+        for a in ALGOS:
+            assert got[a] == r["count"], (a, r, got)
+
+
+def test_english_vectors():
+    T = np.fromfile(os.path.join(GOLDEN, "english_excerpt.txt"), dtype=np.uint8)
+    text = Text.upload(T)
+    for r in load_golden("english_vectors.json")["rows"]:
+        got = gpu_counts(T[r["k"]:r["k"] + r["m"]], text)
+        for a in ALGOS:
+            assert got[a] == r["count"], (a, r, got)
+
+
+def test_documented_deviations(oracle):
+    """Truth (bf.c semantics) where the reference itself deviates: EPSM tail
+    miss (epsm.c:330) and the SO/BNDM straddle over-read (so.c:90, bndm.c:101)."""
+    for r in load_golden("deviations.json")["rows"]:
+        T = oracle.gen_text(r["seed"], r["sigma"], 0, r["n"])
+        P = np.frombuffer(bytes.fromhex(r["P_hex"]), dtype=np.uint8) if "P_hex" in r else T[r["k"]:r["k"] + r["m"]]
+        if "tail_hex" in r:
+            # put the bytes that fool the reference right after the searched range
+            tail = np.frombuffer(bytes.fromhex(r["tail_hex"]), dtype=np.uint8)
+            text = Text.upload(np.concatenate([T, tail]))
+            got = gpu_counts(P, text, off=0, n=r["n"])
+        else:
+            text = Text.upload(T)
+            got = gpu_counts(P, text)
+        for a in ALGOS:
+            assert got[a] == r["truth"], (a, r, got)
+
+
+def test_edges_and_ranges(oracle):
+    T = oracle.gen_text(11, 4, 0, 70000)
+    text = Text.upload(T)
+    # m == n, m > n, n == 0, single byte
+    for a in ALGOS:
+        assert smart_amd.search(a, T[:100], text, off=0, n=100)[0] == 1
+        assert smart_amd.search(a, T[:100], text, off=5, n=50)[0] == 0
+        assert smart_amd.search(a, T[:3], text, off=17, n=0)[0] == 0
+        assert smart_amd.search(a, T[9:10], text, off=9, n=1)[0] == 1
+    # arbitrary sub-ranges (shard-style): count == oracle on the slice
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        off = int(rng.integers(0, 60000))
+        n = int(rng.integers(1, 70000 - off))
+        m = int(rng.choice([1, 2, 5, 16, 33, 70, 300]))
+        k = int(rng.integers(0, 70000 - m))
+        P = T[k:k + m]
+        want = oracle.search("bf", P, T[off:off + n])
+        got = gpu_counts(P, text, off=off, n=n)
+        for a in ALGOS:
+            assert got[a] == want, (a, off, n, m, k, got, want)
+    # errors: m = 0, m > XSIZE, bad range
+    for bad in (T[:0], np.zeros(4201, dtype=np.uint8)):
+        with pytest.raises(smart_amd.SmartGpuError):
+            smart_amd.search("hor", bad, text)
+    with pytest.raises(smart_amd.SmartGpuError):
+        smart_amd.search("hor", T[:4], text, off=69999, n=5)
+
+
+def test_large_patterns_and_periodic_text(oracle):
+    """m up to XSIZE (sets.h:25 goes to 4096), halo > LDS halo, dense overlaps."""
+    T = oracle.gen_text(21, 128, 0, 300000)
+    text = Text.upload(T)
+    for m in (257, 258, 512, 1024, 4096, 4200):
+        for k in (0, 12345, 300000 - m):
+            P = T[k:k + m]
+            got = gpu_counts(P, text)
+            for a in ALGOS:
+                assert got[a] == 1, (a, m, k, got)
+    text.free()
+    A = np.full(100000, ord("a"), dtype=np.uint8)
+    text = Text.upload(A)
+    for m in (1, 2, 31, 32, 33, 64, 300, 1000):
+        want = 100000 - m + 1
+        got = gpu_counts(A[:m], text)
+        for a in ALGOS:
+            assert got[a] == want, (a, m, got)
+    AB = np.resize(np.frombuffer(b"ab", dtype=np.uint8), 65536 + 7)
+    text = Text.upload(AB)
+    for m in (2, 3, 40, 41, 600):
+        want = oracle.search("bf", AB[:m], AB)
+        got = gpu_counts(AB[:m], text)
+        for a in ALGOS:
+            assert got[a] == want, (a, m, got)
+
+
+def test_small_alphabets_dense_matches(oracle):
+    """BASELINE config 3 regime: sigma 2 and 4, m <= 64, many occurrences."""
+    for sigma in (2, 4):
+        T = oracle.gen_text(31 + sigma, sigma, 0, 2_000_000)
+        text = Text.upload(T)
+        for m in (1, 2, 4, 8, 16, 32, 64):
+            P = T[777:777 + m]
+            want = oracle.search("epsm", P, T)
+            got = gpu_counts(P, text)
+            for a in ALGOS:
+                assert got[a] == want, (a, sigma, m, got, want)
+
+
+def test_device_generator_matches_oracle(oracle):
+    for sigma, off, n in ((128, 0, 100000), (2, 12345, 70001), (250, 7, 4099), (256, 8, 64), (4, 3, 1)):
+        text = Text.generate(SEED2, sigma, n, off=off)
+        assert np.array_equal(text.read(0, n), oracle.gen_text(SEED2, sigma, off, n)), (sigma, off, n)
+    unit = oracle.gen_text(1, 128, 0, 1000)
+    text = Text.upload_tiled(unit, 5555, phase=37)
+    assert np.array_equal(text.read(0, 5555), np.resize(np.roll(unit, -37), 5555))
+
+
+def test_plan_slots_and_timing(oracle):
+    T = oracle.gen_text(41, 128, 0, 1 << 20)
+    text = Text.upload(T)
+    pats = [T[k:k + 32] for k in (5, 70000, 999000)]
+    plans = [Plan("hor", p) for p in pats]
+    for i, p in enumerate(plans):
+        p.launch(text, slot=i, timed=True)
+    for i, p in enumerate(plans):
+        c, ms = p.result(i)
+        assert c == oracle.search("hor", pats[i], T)
+        assert ms > 0
+    assert plans[0].kernel_name == "hor_scan"
+
+
+def test_full_size_properties(oracle):
+    """BASELINE config 2 at full size (1 GiB rand128, m in {4,8,32,256}) through
+    size-independent properties: all six kernels agree; shard sums with an (m-1)
+    overlap equal the whole; a 32 MiB slice equals the oracle."""
+    n = 1 << 30
+    text = Text.generate(SEED2, 128, n)
+    for j, m in enumerate((4, 8, 32, 256)):
+        k = oracle.splitmix64(0x0A77E2 + 4096 * j + m) % (n - m)
+        P = text.pattern(k, m)
+        got = gpu_counts(P, text)
+        assert len(set(got.values())) == 1 and got["hor"] >= 1, (m, got)
+        # 4 shards by start offset, each seeing m-1 extra bytes
+        starts = n - m + 1
+        total = 0
+        for g in range(4):
+            a, b = starts * g // 4, starts * (g + 1) // 4
+            total += smart_amd.search("hor", P, text, off=a, n=(b - a) + m - 1)[0]
+        assert total == got["hor"], (m, total, got)
+        # slice around the planted occurrence against the oracle
+        lo = max(0, min(k - (16 << 20), n - (32 << 20)))
+        sl = text.read(lo, 32 << 20)
+        want = oracle.search("hor", P, sl)
+        for a in ("hor", "epsm", "so"):
+            assert smart_amd.search(a, P, text, off=lo, n=32 << 20)[0] == want, (a, m)
