@@ -111,8 +111,9 @@ void smartgpu_last_times(double *pre_ms, double *run_ms);
 smartgpu_plan *smartgpu_plan_create(int algo, const uint8_t *P, uint32_t m, int device);
 void smartgpu_plan_free(smartgpu_plan *p);
 /* Enqueues one search of text[off..off+n) on the device's stream and returns
- * without waiting; the count goes to result slot `slot` (0 <= slot < 4096) of
- * the plan.  With `timed` != 0 the launch is bracketed by HIP events. */
+ * without waiting; the count is ADDED to result slot `slot` (0 <= slot < 4096)
+ * of the plan (slots start at zero; smartgpu_plan_reset() zeroes them again).
+ * With `timed` != 0 the launch is bracketed by HIP events. */
 int smartgpu_plan_launch(smartgpu_plan *p, const smartgpu_text *text, uint64_t off, uint64_t n,
                          int slot, int timed);
 /* Waits for the stream and returns the count of `slot` (and, if the launch was
@@ -120,9 +121,20 @@ int smartgpu_plan_launch(smartgpu_plan *p, const smartgpu_text *text, uint64_t o
 int smartgpu_plan_result(smartgpu_plan *p, int slot, uint64_t *count, double *kernel_ms);
 /* Name of the dominant kernel the plan launches (as rocprofv3 reports it). */
 const char *smartgpu_plan_kernel_name(const smartgpu_plan *p);
-/* Device address of the plan's 4096 uint64 result slots (for an RCCL reduce
- * issued by the caller on the same device). */
+/* Device address of the plan's uint64 result slots (for an RCCL reduce issued
+ * by the caller on the same device). */
 void *smartgpu_plan_result_device_ptr(smartgpu_plan *p);
+/* Zeroes every result slot (stream-ordered). */
+int smartgpu_plan_reset(smartgpu_plan *p);
+/* Makes the plan write its counts to caller-owned DEVICE memory (`nslots`
+ * uint64, zeroed by the caller), e.g. one element of a vector that the caller
+ * reduces across GPUs with RCCL.  NULL restores the plan's own slots. */
+int smartgpu_plan_set_result_buffer(smartgpu_plan *p, void *device_u64, int nslots);
+
+/* ---- stream timing (hipEvents on the stream the kernels run on) ------------ */
+int smartgpu_stream_mark(int device, int which /* 0 = begin, 1 = end */);
+int smartgpu_stream_elapsed_ms(int device, double *ms); /* waits for mark 1 */
+void *smartgpu_stream_handle(int device);               /* hipStream_t of the library on `device` */
 
 /* Host-side preprocessing exposed for tests (same tables the kernels stage in
  * LDS): writes up to `cap` 32-bit entries, returns the number written or <0.

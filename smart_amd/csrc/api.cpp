@@ -51,6 +51,7 @@ struct DeviceCtx {
     uint8_t* pinned = nullptr;      // staging for uploads
     size_t pinned_bytes = 0;
     unsigned long long* pinned_count = nullptr;  // 8-byte readback slot
+    hipEvent_t mark[2] = {nullptr, nullptr};     // smartgpu_stream_mark()
 };
 DeviceCtx g_dev[kMaxDevices];
 
@@ -103,7 +104,11 @@ struct smartgpu_plan {
     uint32_t m = 0;
     uint32_t halo = 0;
     uint8_t* blob = nullptr;               // device: pattern + tables
-    unsigned long long* results = nullptr; // device: kResultSlots counters
+    unsigned long long* results = nullptr; // device: kResultSlots counters (library-owned)
+    unsigned long long* ext_results = nullptr; // caller-owned device buffer, if set
+    int ext_slots = 0;
+    unsigned long long* slot_ptr(int slot) const { return ext_results ? ext_results + slot : results + slot; }
+    int num_slots() const { return ext_results ? ext_slots : sg::kResultSlots; }
     hipEvent_t ev0[sg::kResultSlots] = {}; // created lazily for timed launches
     hipEvent_t ev1[sg::kResultSlots] = {};
     bool timed[sg::kResultSlots] = {};
@@ -221,7 +226,7 @@ sg::ScanArgs make_args(const smartgpu_plan* p, const smartgpu_text* text, uint64
     a.m = p->m;
     a.halo = p->halo;
     a.blob = p->blob;
-    a.count = p->results + slot;
+    a.count = p->slot_ptr(slot);
     return a;
 }
 
@@ -392,12 +397,11 @@ int smartgpu_plan_launch(smartgpu_plan* p, const smartgpu_text* text, uint64_t o
                          int slot, int timed)
 {
     if (!p || !text) { set_error("plan or text is NULL"); return SMARTGPU_ERR_ARG; }
-    if (slot < 0 || slot >= sg::kResultSlots) { set_error("slot %d out of range", slot); return SMARTGPU_ERR_ARG; }
+    if (slot < 0 || slot >= p->num_slots()) { set_error("slot %d out of range", slot); return SMARTGPU_ERR_ARG; }
     if (text->device != p->device) { set_error("plan is on device %d, text on %d", p->device, text->device); return SMARTGPU_ERR_ARG; }
     if (off > text->n || n > text->n - off) { set_error("range outside the text"); return SMARTGPU_ERR_ARG; }
     DeviceCtx* d = device_ctx(p->device);
     if (!d) return SMARTGPU_ERR_HIP;
-    HIP_TRY(hipMemsetAsync(p->results + slot, 0, sizeof(unsigned long long), d->stream), return SMARTGPU_ERR_HIP);
     p->timed[slot] = timed != 0;
     if (timed) {
         if (!p->ev0[slot]) {
@@ -414,10 +418,10 @@ int smartgpu_plan_launch(smartgpu_plan* p, const smartgpu_text* text, uint64_t o
 
 int smartgpu_plan_result(smartgpu_plan* p, int slot, uint64_t* count, double* kernel_ms)
 {
-    if (!p || slot < 0 || slot >= sg::kResultSlots) { set_error("bad plan/slot"); return SMARTGPU_ERR_ARG; }
+    if (!p || slot < 0 || slot >= p->num_slots()) { set_error("bad plan/slot"); return SMARTGPU_ERR_ARG; }
     DeviceCtx* d = device_ctx(p->device);
     if (!d) return SMARTGPU_ERR_HIP;
-    HIP_TRY(hipMemcpyAsync(d->pinned_count, p->results + slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, d->stream),
+    HIP_TRY(hipMemcpyAsync(d->pinned_count, p->slot_ptr(slot), sizeof(unsigned long long), hipMemcpyDeviceToHost, d->stream),
             return SMARTGPU_ERR_HIP);
     HIP_TRY(hipStreamSynchronize(d->stream), return SMARTGPU_ERR_HIP);
     if (count) *count = *d->pinned_count;
@@ -437,7 +441,51 @@ const char* smartgpu_plan_kernel_name(const smartgpu_plan* p)
     return p ? sg::scan_kernel_name(p->algo, p->m) : nullptr;
 }
 
-void* smartgpu_plan_result_device_ptr(smartgpu_plan* p) { return p ? p->results : nullptr; }
+void* smartgpu_plan_result_device_ptr(smartgpu_plan* p) { return p ? p->slot_ptr(0) : nullptr; }
+
+int smartgpu_plan_reset(smartgpu_plan* p)
+{
+    if (!p) { set_error("plan is NULL"); return SMARTGPU_ERR_ARG; }
+    DeviceCtx* d = device_ctx(p->device);
+    if (!d) return SMARTGPU_ERR_HIP;
+    HIP_TRY(hipMemsetAsync(p->slot_ptr(0), 0, sizeof(unsigned long long) * p->num_slots(), d->stream),
+            return SMARTGPU_ERR_HIP);
+    return SMARTGPU_OK;
+}
+
+int smartgpu_plan_set_result_buffer(smartgpu_plan* p, void* device_u64, int nslots)
+{
+    if (!p || (device_u64 && (nslots < 1 || nslots > sg::kResultSlots))) { set_error("bad result buffer"); return SMARTGPU_ERR_ARG; }
+    p->ext_results = static_cast<unsigned long long*>(device_u64);
+    p->ext_slots = device_u64 ? nslots : 0;
+    return SMARTGPU_OK;
+}
+
+int smartgpu_stream_mark(int device, int which)
+{
+    DeviceCtx* d = device_ctx(device);
+    if (!d || which < 0 || which > 1) return SMARTGPU_ERR_ARG;
+    if (!d->mark[which]) HIP_TRY(hipEventCreate(&d->mark[which]), return SMARTGPU_ERR_HIP);
+    HIP_TRY(hipEventRecord(d->mark[which], d->stream), return SMARTGPU_ERR_HIP);
+    return SMARTGPU_OK;
+}
+
+int smartgpu_stream_elapsed_ms(int device, double* ms)
+{
+    DeviceCtx* d = device_ctx(device);
+    if (!d || !ms || !d->mark[0] || !d->mark[1]) { set_error("stream marks not set"); return SMARTGPU_ERR_ARG; }
+    HIP_TRY(hipEventSynchronize(d->mark[1]), return SMARTGPU_ERR_HIP);
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, d->mark[0], d->mark[1]), return SMARTGPU_ERR_HIP);
+    *ms = f;
+    return SMARTGPU_OK;
+}
+
+void* smartgpu_stream_handle(int device)
+{
+    DeviceCtx* d = device_ctx(device);
+    return d ? static_cast<void*>(d->stream) : nullptr;
+}
 
 /* ---- one-shot searches ------------------------------------------------- */
 int smartgpu_search64(int algo, const uint8_t* P, uint32_t m, const smartgpu_text* text,

@@ -59,6 +59,11 @@ def lib():
         "smartgpu_plan_kernel_name": (C.c_char_p, [vp]),
         "smartgpu_plan_result_device_ptr": (vp, [vp]),
         "smartgpu_build_table": (i32, [i32, vp, u32, vp, u32]),
+        "smartgpu_plan_reset": (i32, [vp]),
+        "smartgpu_plan_set_result_buffer": (i32, [vp, vp, i32]),
+        "smartgpu_stream_mark": (i32, [i32, i32]),
+        "smartgpu_stream_elapsed_ms": (i32, [i32, C.POINTER(C.c_double)]),
+        "smartgpu_stream_handle": (vp, [i32]),
     }
     for a in ALGOS:
         sig["smartgpu_%s_search" % a] = (i32, [vp, i32, vp, i32])
@@ -172,6 +177,14 @@ class Plan:
             raise _err("plan_result")
         return int(c.value), float(ms.value)
 
+    def reset(self):
+        if lib().smartgpu_plan_reset(self._h) != 0:
+            raise _err("plan_reset")
+
+    def set_result_buffer(self, device_ptr, nslots=1):
+        if lib().smartgpu_plan_set_result_buffer(self._h, device_ptr, nslots) != 0:
+            raise _err("plan_set_result_buffer")
+
     @property
     def kernel_name(self):
         return lib().smartgpu_plan_kernel_name(self._h).decode()
@@ -212,6 +225,23 @@ def search_host(algo, P, T):
     P = _u8(P)
     T = _u8(T)
     return getattr(lib(), "smartgpu_%s_search" % algo)(P.ctypes.data, len(P), T.ctypes.data, len(T))
+
+
+def device_sync(device=0):
+    if lib().smartgpu_device_sync(device) != 0:
+        raise _err("device_sync")
+
+
+def stream_mark(device, which):
+    if lib().smartgpu_stream_mark(device, which) != 0:
+        raise _err("stream_mark")
+
+
+def stream_elapsed_ms(device):
+    ms = C.c_double(0.0)
+    if lib().smartgpu_stream_elapsed_ms(device, C.byref(ms)) != 0:
+        raise _err("stream_elapsed_ms")
+    return float(ms.value)
 
 
 def build_table(which, P):
