@@ -136,6 +136,10 @@ int smartgpu_stream_mark(int device, int which /* 0 = begin, 1 = end */);
 int smartgpu_stream_elapsed_ms(int device, double *ms); /* waits for mark 1 */
 void *smartgpu_stream_handle(int device);               /* hipStream_t of the library on `device` */
 
+/* Kernel-variant selection for experiments and A/B measurements (not needed in
+ * normal use): key 0 = Horspool variant, 0 auto / 1 flat LDS tile / 2 bank-private. */
+int smartgpu_tune(int key, int value);
+
 /* Host-side preprocessing exposed for tests (same tables the kernels stage in
  * LDS): writes up to `cap` 32-bit entries, returns the number written or <0.
  *   which: 0 Horspool bad-char (256)      hor.c:26-30 / bm.c:27-33

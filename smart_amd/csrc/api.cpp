@@ -153,6 +153,17 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         const uint8_t* b = static_cast<const uint8_t*>(p);
         blob.insert(blob.end(), b, b + bytes);
     };
+    // first min(m,16) pattern bytes as 4 dwords + 4 byte masks (packed kernel)
+    auto append_fingerprint = [&]() {
+        uint32_t fp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint8_t* fb = reinterpret_cast<uint8_t*>(fp);
+        const uint32_t F = std::min<uint32_t>(m, 16);
+        for (uint32_t i = 0; i < F; ++i) {
+            fb[i] = P[i];
+            fb[16 + i] = 0xFF;
+        }
+        append(fp, sizeof fp);
+    };
     *halo = std::min<uint32_t>(m - 1, sg::kHaloMax);
     switch (algo) {
         case SMARTGPU_HOR: {
@@ -161,6 +172,10 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             for (int c = 0; c < 256; ++c)
                 tab[c] = static_cast<uint16_t>(bc[c]) | (c == P[m - 1] ? 0x8000u : 0u);
             append(tab.data(), 512);
+            uint8_t tab8[256];  // plain u8 shifts for the bank-private kernel (m <= 255)
+            for (int c = 0; c < 256; ++c) tab8[c] = static_cast<uint8_t>(bc[c] > 255 ? 255 : bc[c]);
+            append(tab8, 256);
+            append_fingerprint();  // m <= 4 regime: packed compare of the whole window
             break;
         }
         case SMARTGPU_BM: {
@@ -190,17 +205,9 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             append(B.data(), 1024);
             break;
         }
-        case SMARTGPU_EPSM: {
-            uint32_t fp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            uint8_t* fb = reinterpret_cast<uint8_t*>(fp);
-            const uint32_t F = std::min<uint32_t>(m, 16);
-            for (uint32_t i = 0; i < F; ++i) {
-                fb[i] = P[i];
-                fb[16 + i] = 0xFF;
-            }
-            append(fp, sizeof fp);
+        case SMARTGPU_EPSM:
+            append_fingerprint();
             break;
-        }
     }
     blob.resize((blob.size() + 255) & ~size_t(255), 0);
     return blob;
@@ -225,6 +232,7 @@ sg::ScanArgs make_args(const smartgpu_plan* p, const smartgpu_text* text, uint64
     a.s_end = (n >= p->m) ? off + n - p->m + 1 : off;  // no window fits: empty range
     a.m = p->m;
     a.halo = p->halo;
+    a.fp_off = 0;
     a.blob = p->blob;
     a.count = p->slot_ptr(slot);
     return a;
@@ -478,6 +486,13 @@ int smartgpu_stream_elapsed_ms(int device, double* ms)
     float f = 0.f;
     HIP_TRY(hipEventElapsedTime(&f, d->mark[0], d->mark[1]), return SMARTGPU_ERR_HIP);
     *ms = f;
+    return SMARTGPU_OK;
+}
+
+int smartgpu_tune(int key, int value)
+{
+    if (key < 0 || key >= 8) { set_error("tune key %d out of range", key); return SMARTGPU_ERR_ARG; }
+    sg::g_tune[key] = value;
     return SMARTGPU_OK;
 }
 

@@ -100,12 +100,33 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
 
     const uint64_t e_begin = a.s_begin + m - 1, e_end = a.s_end + m - 1;
     uint32_t hits = 0;
-    for (uint64_t t = tile_first + blockIdx.x; t < tile_first + ntiles; t += gridDim.x) {
+    const uint64_t t_end = tile_first + ntiles;
+    static_assert(TB == THREADS * 64, "prefetch registers are written out for L = 64");
+    uint4 p0, p1, p2, p3, ph;  // prefetch registers: 4 tile rows + one halo chunk
+    const bool halo_lane = threadIdx.x * 16u < H16;
+    auto issue = [&](uint64_t tile0) {
+        const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
+        p0 = *reinterpret_cast<const uint4*>(src);
+        p1 = *reinterpret_cast<const uint4*>(src + THREADS * 16);
+        p2 = *reinterpret_cast<const uint4*>(src + THREADS * 32);
+        p3 = *reinterpret_cast<const uint4*>(src + THREADS * 48);
+        if (halo_lane) ph = *reinterpret_cast<const uint4*>(src - H16);
+    };
+    uint64_t t = tile_first + blockIdx.x;
+    issue(t * TB);
+    for (; t < t_end; t += gridDim.x) {
         const uint64_t tile0 = t * TB;
         __syncthreads();  // previous tile fully consumed (and tables visible)
-        stage_bytes<THREADS>(txt, a.text + tile0 - H16, H16);
-        stage_tile<THREADS, TB>(txt + H16, a.text + tile0);
+        {
+            uint8_t* dst = txt + H16 + threadIdx.x * 16u;
+            *reinterpret_cast<uint4*>(dst) = p0;
+            *reinterpret_cast<uint4*>(dst + THREADS * 16) = p1;
+            *reinterpret_cast<uint4*>(dst + THREADS * 32) = p2;
+            *reinterpret_cast<uint4*>(dst + THREADS * 48) = p3;
+            if (halo_lane) *reinterpret_cast<uint4*>(txt + threadIdx.x * 16u) = ph;
+        }
         __syncthreads();
+        if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
         const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
         const uint64_t lo = seg > e_begin ? seg : e_begin;
         const uint64_t hi = seg + L < e_end ? seg + L : e_end;
@@ -125,6 +146,131 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
                     hits += ok;
                 }
                 e += ent & 0x7FFFu;
+            }
+        }
+    }
+    flush_hits(hits, a.count);
+}
+
+// ---------------------------------------------------------------------------
+// Horspool, bank-private LDS layout (m <= 255).
+//
+// hor_scan above is LDS-bound for short patterns: rocprofv3 shows the LDS busy
+// 95 % of the kernel at m=4 with 78 % of those cycles bank conflicts (lanes
+// read random bytes of a flat tile and random entries of one shared table).
+// Here every lane reads only its OWN bank:
+//   * text: the 64-byte run of lane q is stored down column q of a
+//     [16 rows][288 columns] dword matrix (row stride 1152 B = 9 * 128 B, so the
+//     bank of a dword is column % 32 = q % 32 whatever the row).  Columns 0..31
+//     hold the back halo (only the last ceil(H/64) are filled), 32+q is lane q.
+//   * table: 32 copies of the 256-entry u8 shift table, copy b wholly in bank b
+//     (8 KiB); lane l reads copy l % 32.
+// Lanes l and l+32 of a wave share a bank but sit in different halves of the
+// wave64 access, so reads are conflict-free by construction.
+// The transpose happens on the way in: each wave loads its 4 KiB coalesced
+// (4 x global_load_dwordx4), then lane (quad, r) writes register (r+t)%4 in
+// step t, so the four lanes of a quad — whose registers hold the same four
+// segments — hit two banks twice (a 2-way ds_write_b32 conflict is free,
+// MI355X_MICROARCH.md §LDS) instead of one bank four times.
+// ---------------------------------------------------------------------------
+constexpr int kBpThreads = 256, kBpL = 64;
+constexpr int kBpHaloCols = 32;                        // columns reserved for the back halo
+constexpr int kBpCols = kBpHaloCols + kBpThreads;      // 288
+constexpr int kBpRowBytes = kBpCols * 4;               // 1152
+constexpr int kBpTextBytes = (kBpL / 4) * kBpRowBytes; // 18432
+constexpr int kBpHB = kBpHaloCols * kBpL;              // P-coordinate of tile-local byte 0
+constexpr int kBpTabBytes = 8192;
+
+// LDS byte address of P-coordinate `P` (P = kBpHB + tile-local offset)
+__device__ __forceinline__ uint32_t bp_addr(uint32_t P)
+{
+    return ((P & 63u) >> 2) * kBpRowBytes + (P >> 6) * 4u + (P & 3u);
+}
+
+__global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t tile_first,
+                                                          uint32_t ntiles)
+{
+    constexpr int TB = kBpThreads * kBpL;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m, H = a.halo, H16 = round16(H);
+    uint8_t* ptab = smem;                          // bank-private u8 shift tables
+    uint8_t* ptail = smem + kBpTabBytes;           // ptail[H-k] == P[m-1-k]
+    uint8_t* txt = ptail + round16(H + 1);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+
+    {   // 64 rows (4 chars each) x 32 banks: every bank gets the same packed dword
+        const uint32_t* g = reinterpret_cast<const uint32_t*>(a.blob + kTableOff + 512);
+        uint32_t* t32 = reinterpret_cast<uint32_t*>(ptab);
+        for (uint32_t i = tid; i < 2048; i += kBpThreads) t32[i] = g[i >> 5];
+    }
+    for (uint32_t i = tid; i <= H; i += kBpThreads) ptail[i] = a.blob[m - 1 - H + i];
+    const uint32_t plast = a.blob[m - 1];
+    const uint32_t my_tab = (lane & 31u) * 4u;
+
+    const uint64_t e_begin = a.s_begin + m - 1, e_end = a.s_end + m - 1;
+    uint32_t hits = 0;
+    const uint64_t t_end = tile_first + ntiles;
+    const uint32_t r = lane & 3u;
+    uint32_t* t32 = reinterpret_cast<uint32_t*>(txt);
+    // prefetch registers: this wave's 4 KiB of the tile (coalesced) + one halo chunk
+    uint4 v0, v1, v2, v3, hv;
+    auto issue = [&](uint64_t tile0) {
+        const uint8_t* src = a.text + tile0 + wave * 4096u + lane * 16u;
+        v0 = *reinterpret_cast<const uint4*>(src);
+        v1 = *reinterpret_cast<const uint4*>(src + 1024);
+        v2 = *reinterpret_cast<const uint4*>(src + 2048);
+        v3 = *reinterpret_cast<const uint4*>(src + 3072);
+        if (tid * 16u < H16) hv = *reinterpret_cast<const uint4*>(a.text + tile0 - H16 + tid * 16u);
+    };
+    uint64_t t = tile_first + blockIdx.x;
+    issue(t * TB);
+    for (; t < t_end; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();
+        {   // ---- transposing stores of the prefetched tile
+#pragma unroll
+            for (uint32_t st = 0; st < 4; ++st) {
+                const uint32_t k = (r + st) & 3u;
+                uint4 x;
+                x.x = k == 0 ? v0.x : k == 1 ? v1.x : k == 2 ? v2.x : v3.x;
+                x.y = k == 0 ? v0.y : k == 1 ? v1.y : k == 2 ? v2.y : v3.y;
+                x.z = k == 0 ? v0.z : k == 1 ? v1.z : k == 2 ? v2.z : v3.z;
+                x.w = k == 0 ? v0.w : k == 1 ? v1.w : k == 2 ? v2.w : v3.w;
+                const uint32_t col = kBpHaloCols + wave * 64u + k * 16u + (lane >> 2);
+                const uint32_t w0 = (4u * r) * kBpCols + col;  // dword index of row 4r
+                t32[w0] = x.x;
+                t32[w0 + kBpCols] = x.y;
+                t32[w0 + 2 * kBpCols] = x.z;
+                t32[w0 + 3 * kBpCols] = x.w;
+            }
+            if (tid * 16u < H16) {  // back halo: bytes [tile0-H16, tile0)
+                const uint32_t P0 = kBpHB - H16 + tid * 16u;
+                const uint32_t w0 = ((P0 & 63u) >> 2) * kBpCols + (P0 >> 6);
+                t32[w0] = hv.x;
+                t32[w0 + kBpCols] = hv.y;
+                t32[w0 + 2 * kBpCols] = hv.z;
+                t32[w0 + 3 * kBpCols] = hv.w;
+            }
+        }
+        __syncthreads();
+        if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
+        const uint64_t seg = tile0 + (uint64_t)tid * kBpL;
+        const uint64_t lo = seg > e_begin ? seg : e_begin;
+        const uint64_t hi = seg + kBpL < e_end ? seg + kBpL : e_end;
+        if (lo < hi) {
+            uint32_t e = (uint32_t)(lo - tile0) + kBpHB;  // P-coordinates
+            const uint32_t ehi = (uint32_t)(hi - tile0) + kBpHB;
+            {
+                while (e < ehi) {
+                    const uint32_t c = txt[bp_addr(e)];
+                    const uint32_t shift = ptab[(c >> 2) * 128u + my_tab + (c & 3u)];
+                    if (c == plast) {
+                        uint32_t k = 1;
+                        while (k <= H && ptail[H - k] == txt[bp_addr(e - k)]) ++k;
+                        hits += k > H;  // m-1 == H here (m <= 255): the whole window was compared
+                    }
+                    e += shift;
+                }
             }
         }
     }
@@ -384,77 +530,103 @@ __global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a, uint64_t tile_fi
 }
 
 // ---------------------------------------------------------------------------
-// EPSM — packed matching  (reference: src/algos/epsm.c; the SSE regimes map to
-// one VALU scheme here).  Each lane takes 16 consecutive start positions per
-// step straight from registers: 32 text bytes (its own 16 and the next 16) give
-// every unaligned dword via v_alignbyte_b32; the first F = min(m,16) pattern
-// bytes are compared as up to four masked dwords at all 16 alignments, later
-// dwords only when some lane of the wave still has a candidate; m > 16 verifies
-// the rest from memory.  No LDS, no tables beyond the 4-dword fingerprint.
-// Matches are reduced with popcount over the per-lane candidate masks.
+// EPSM — packed matching  (reference: src/algos/epsm.c; its SSE regimes —
+// broadcast compare, mpsadbw 4-byte filter, hashed 8-byte blocks — map to one
+// VALU scheme here: compare the first F = min(m,16) pattern bytes, packed as up
+// to four masked dwords, at EVERY alignment; verify the rest only on a hit).
+//
+// Each lane takes 16 consecutive start positions per row straight from
+// registers: 32 text bytes (its own 16 and the next 16) give the text dword at
+// each of its 16 byte offsets via v_alignbyte_b32.  Deeper fingerprint dwords
+// are compared only when some lane of the wave still has a candidate (ballot);
+// m > 16 verifies bytes 16.. from memory.  Hits are popcounts of the per-lane
+// candidate masks.  No LDS, no table beyond the 4-dword fingerprint.
+// ROWS rows (ROWS * 4 KiB per workgroup) are loaded before any is processed so
+// that enough bytes are in flight per CU to cover HBM latency.
 // ---------------------------------------------------------------------------
-template <int THREADS>
-__global__ __launch_bounds__(THREADS) void epsm_scan(ScanArgs a, uint64_t row_first,
-                                                     uint64_t nrows)
-{
-    const uint32_t m = a.m;
-    const uint32_t* fpw = reinterpret_cast<const uint32_t*>(a.blob + kTableOff);
-    const uint32_t f0 = fpw[0], f1 = fpw[1], f2 = fpw[2], f3 = fpw[3];
-    const uint32_t k0 = fpw[4], k1 = fpw[5], k2 = fpw[6], k3 = fpw[7];
-    const uint32_t nd = (m >= 13) ? 4 : (m + 3) / 4;  // fingerprint dwords
+struct EpsmFp { uint32_t f0, f1, f2, f3, k0, k1, k2, k3, nd, m; };
 
-    uint32_t hits = 0;
-    // a "row" is THREADS*16 consecutive absolute text offsets
-    for (uint64_t r = row_first + blockIdx.x; r < row_first + nrows; r += gridDim.x) {
-        const uint64_t p0 = (r * THREADS + threadIdx.x) * 16;
-        const uint4 A = *reinterpret_cast<const uint4*>(a.text + p0);
-        const uint4 Bv = *reinterpret_cast<const uint4*>(a.text + p0 + 16);
-        const uint32_t d[8] = {A.x, A.y, A.z, A.w, Bv.x, Bv.y, Bv.z, Bv.w};
-        // positions p0+k inside [s_begin, s_end)
+// text dword at byte offset x (compile-time after unrolling) of the 8-dword window d[]
+#define SG_W(x) (((x) & 3) == 0 ? d[(x) >> 2] \
+                                : __builtin_amdgcn_alignbyte(d[((x) >> 2) + 1], d[(x) >> 2], (x) & 3))
+
+static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const EpsmFp& fp,
+                                                    const uint4& A, const uint4& Bv, uint64_t p0)
+{
+    const uint32_t d[8] = {A.x, A.y, A.z, A.w, Bv.x, Bv.y, Bv.z, Bv.w};
+    // offsets k with p0+k inside [s_begin, s_end)
+    uint32_t cand = 0xFFFFu;
+    if (p0 < a.s_begin || p0 + 16 > a.s_end) {
         const uint64_t lo64 = a.s_begin > p0 ? a.s_begin - p0 : 0;
         const uint64_t hi64 = a.s_end > p0 ? a.s_end - p0 : 0;
         const uint32_t lo = lo64 > 16 ? 16u : (uint32_t)lo64;
         const uint32_t hi = hi64 > 16 ? 16u : (uint32_t)hi64;
-        uint32_t cand = (hi > lo) ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
-
-        // w(x) = text dword at byte offset x of the 32-byte window
-#define SG_W(x) (((x) & 3) == 0 ? d[(x) >> 2] \
-                                : __builtin_amdgcn_alignbyte(d[((x) >> 2) + 1], d[(x) >> 2], (x) & 3))
-        {
-            uint32_t eq = 0;
+        cand = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+    }
+    {
+        uint32_t eq = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) eq |= ((SG_W(k) & k0) == f0) ? (1u << k) : 0u;
-            cand &= eq;
-        }
-        if (nd > 1 && __any(cand != 0)) {
-            uint32_t eq = 0;
+        for (int k = 0; k < 16; ++k) eq |= ((SG_W(k) & fp.k0) == fp.f0) ? (1u << k) : 0u;
+        cand &= eq;
+    }
+    if (fp.nd > 1 && __any(cand != 0)) {
+        uint32_t eq = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) eq |= ((SG_W(k + 4) & k1) == f1) ? (1u << k) : 0u;
-            cand &= eq;
-            if (nd > 2 && __any(cand != 0)) {
-                eq = 0;
+        for (int k = 0; k < 16; ++k) eq |= ((SG_W(k + 4) & fp.k1) == fp.f1) ? (1u << k) : 0u;
+        cand &= eq;
+        if (fp.nd > 2 && __any(cand != 0)) {
+            eq = 0;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) eq |= ((SG_W(k + 8) & k2) == f2) ? (1u << k) : 0u;
-                cand &= eq;
-                if (nd > 3) {
-                    eq = 0;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        eq |= ((SG_W(k + 12) & k3) == f3) ? (1u << k) : 0u;
-                    cand &= eq;
-                }
+            for (int k = 0; k < 16; ++k) {
+                bool e2 = (SG_W(k + 8) & fp.k2) == fp.f2;
+                if (fp.nd > 3) e2 = e2 && ((SG_W(k + 12) & fp.k3) == fp.f3);
+                eq |= e2 ? (1u << k) : 0u;
             }
+            cand &= eq;
         }
-#undef SG_W
-        if (m > 16) {
+        if (fp.m > 16) {
             uint32_t c = cand;
             while (c) {
                 const uint32_t k = __builtin_ctz(c);
                 c &= c - 1;
-                if (!global_equal(a.text + p0 + k + 16, a.blob + 16, m - 16)) cand &= ~(1u << k);
+                if (!global_equal(a.text + p0 + k + 16, a.blob + 16, fp.m - 16)) cand &= ~(1u << k);
             }
         }
-        hits += __popc(cand);
+    }
+    return __popc(cand);
+}
+#undef SG_W
+
+// ALGO only tags the instantiation (rocprofv3 shows packed_scan<256, 4, 5> for
+// EPSM and packed_scan<256, 4, 0> for Horspool's m <= 4 regime, see launch_scan).
+template <int THREADS, int ROWS, int ALGO>
+__global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_first,
+                                                       uint64_t nrows)
+{
+    const uint32_t* fpw = reinterpret_cast<const uint32_t*>(a.blob + a.fp_off);
+    EpsmFp fp;
+    fp.f0 = fpw[0]; fp.f1 = fpw[1]; fp.f2 = fpw[2]; fp.f3 = fpw[3];
+    fp.k0 = fpw[4]; fp.k1 = fpw[5]; fp.k2 = fpw[6]; fp.k3 = fpw[7];
+    fp.m = a.m;
+    fp.nd = (a.m >= 13) ? 4 : (a.m + 3) / 4;  // fingerprint dwords
+
+    uint32_t hits = 0;
+    // a "row" is THREADS*16 consecutive absolute text offsets; a workgroup takes
+    // ROWS consecutive rows per step
+    for (uint64_t g = (uint64_t)blockIdx.x * ROWS; g < nrows; g += (uint64_t)gridDim.x * ROWS) {
+        uint4 A[ROWS], B[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const uint64_t r = g + j < nrows ? g + j : nrows - 1;  // clamp, ignored below
+            const uint8_t* src = a.text + ((row_first + r) * THREADS + threadIdx.x) * 16;
+            A[j] = *reinterpret_cast<const uint4*>(src);
+            B[j] = *reinterpret_cast<const uint4*>(src + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            if (g + j < nrows)
+                hits += epsm_row(a, fp, A[j], B[j], ((row_first + g + j) * THREADS + threadIdx.x) * 16);
+        }
     }
     flush_hits(hits, a.count);
 }
@@ -543,6 +715,8 @@ hipError_t launch_tiled(K kernel, const ScanArgs& a, TileRange tr, int threads, 
 
 }  // namespace
 
+int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 // tile shapes (threads, bytes per lane)
 constexpr int kHorT = 256, kHorL = 64;
 constexpr int kBmT = 256, kBmL = 64;
@@ -551,17 +725,55 @@ constexpr int kSoT = 256, kSoL = 80;
 constexpr int kKmpT = 128, kKmpL = 272;
 constexpr int kEpsmT = 256;
 
-const char* scan_kernel_name(int algo, uint32_t)
+static int hor_regime(uint32_t m);
+
+const char* scan_kernel_name(int algo, uint32_t m)
 {
     switch (algo) {
-        case SMARTGPU_HOR: return "hor_scan";
+        case SMARTGPU_HOR: {
+            const int r = hor_regime(m);
+            return r == 3 ? "packed_scan" : r == 2 ? "hor_scan_bp" : "hor_scan";
+        }
         case SMARTGPU_BM: return "bm_scan";
         case SMARTGPU_KMP: return "kmp_scan";
         case SMARTGPU_SO: return "so_scan";
         case SMARTGPU_BNDM: return "bndm_scan";
-        case SMARTGPU_EPSM: return "epsm_scan";
+        case SMARTGPU_EPSM: return "packed_scan";
     }
     return "?";
+}
+
+// The packed matcher; `a.blob` must carry the fingerprint at kTableOff (EPSM
+// layout) — Horspool's blob carries it after its own tables (api.cpp).
+template <int ALGO>
+static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stream)
+{
+    const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kEpsmT * 16);
+    if (tr.count == 0) return hipSuccess;
+    const int rows = g_tune[2] ? g_tune[2] : 4;  // rows in flight per workgroup step
+    uint64_t grid = ((uint64_t)tr.count + rows - 1) / rows;
+    const uint64_t cap = (uint64_t)num_cus * 8;
+    if (grid > cap) grid = cap;
+    if (rows == 1)
+        hipLaunchKernelGGL((packed_scan<kEpsmT, 1, ALGO>), dim3((uint32_t)grid), dim3(kEpsmT), 0, stream, a, tr.first, (uint64_t)tr.count);
+    else if (rows == 2)
+        hipLaunchKernelGGL((packed_scan<kEpsmT, 2, ALGO>), dim3((uint32_t)grid), dim3(kEpsmT), 0, stream, a, tr.first, (uint64_t)tr.count);
+    else
+        hipLaunchKernelGGL((packed_scan<kEpsmT, 4, ALGO>), dim3((uint32_t)grid), dim3(kEpsmT), 0, stream, a, tr.first, (uint64_t)tr.count);
+    return hipGetLastError();
+}
+
+// Horspool regimes (rand128, 1 GiB, measured): m <= 4 packed compare at every
+// alignment (the window is one dword: the skip loop degenerates, SURVEY.md §7
+// "hybrid"), 5..7 bank-private LDS layout, >= 8 flat LDS tile.
+static int hor_regime(uint32_t m)
+{
+    const int v = g_tune[0];  // 0 auto, 1 flat, 2 bank-private, 3 packed
+    if (v == 3) return m <= 16 ? 3 : 1;
+    if (v == 2) return m <= 255 ? 2 : 1;
+    if (v == 1) return 1;
+    if (m <= 4) return 3;
+    return m < 8 ? 2 : 1;
 }
 
 hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream)
@@ -571,6 +783,17 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
     switch (algo) {
         case SMARTGPU_HOR: {
             const uint32_t H = a.halo;
+            const int regime = hor_regime(m);
+            if (regime == 3) {
+                ScanArgs b = a;
+                b.fp_off = kTableOff + 768;  // fingerprint sits after the u16 and u8 tables
+                return launch_packed<SMARTGPU_HOR>(b, num_cus, stream);
+            }
+            if (regime == 2) {
+                const size_t lds = kBpTabBytes + r16(H + 1) + kBpTextBytes;
+                const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBpThreads * kBpL);
+                return launch_tiled(hor_scan_bp, a, tr, kBpThreads, lds, 5, num_cus, stream);
+            }
             const size_t lds = 512 + r16(H + 1) + r16(H) + (size_t)kHorT * kHorL;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
             return launch_tiled(hor_scan<kHorT, kHorL>, a, tr, kHorT, lds, 8, num_cus, stream);
@@ -598,13 +821,9 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             return launch_tiled(kmp_scan<kKmpT, kKmpL>, a, tr, kKmpT, lds, 3, num_cus, stream);
         }
         case SMARTGPU_EPSM: {
-            const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kEpsmT * 16);
-            if (tr.count == 0) return hipSuccess;
-            uint64_t grid = (uint64_t)num_cus * 8;
-            if (grid > tr.count) grid = tr.count;
-            hipLaunchKernelGGL(epsm_scan<kEpsmT>, dim3((uint32_t)grid), dim3(kEpsmT), 0, stream, a,
-                               tr.first, (uint64_t)tr.count);
-            return hipGetLastError();
+            ScanArgs b = a;
+            b.fp_off = kTableOff;
+            return launch_packed<SMARTGPU_EPSM>(b, num_cus, stream);
         }
     }
     return hipErrorInvalidValue;

@@ -25,12 +25,13 @@ struct ScanArgs {
     uint64_t s_begin, s_end;    // start positions to count: s_begin <= s < s_end (s_end <= n-m+1)
     uint32_t m;                 // pattern length
     uint32_t halo;              // skip kernels: back-halo H = min(m-1, kHaloMax); serial: forward halo
+    uint32_t fp_off;            // packed kernel: blob offset of the fingerprint (set by launch_scan)
     const uint8_t* blob;        // device: [pattern kPatternBytes][tables ...]
     unsigned long long* count;  // device result slot (pre-zeroed)
 };
 
 // Byte offsets of the tables inside the blob, after the pattern slot.
-//  HOR : u16 tab[256]   shift | 0x8000 if c == P[m-1]
+//  HOR : u16 tab[256]   shift | 0x8000 if c == P[m-1]; u8 tab8[256]; fingerprint (as EPSM)
 //  BM  : u16 bc[256], u16 gs[m]
 //  KMP : i16 next[m+1]
 //  SO  : u32 S[256]
@@ -45,6 +46,9 @@ struct LaunchInfo {
 // Enqueue the scan for `algo` on `stream`; returns hipSuccess or the launch error.
 hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream);
 const char* scan_kernel_name(int algo, uint32_t m);
+
+// tuning knobs (smartgpu_tune): [0] HOR variant 0 auto / 1 flat / 2 bank-private
+extern int g_tune[8];
 
 // text generators / helpers (device side)
 hipError_t launch_generate(uint8_t* dst, uint64_t seed, int sigma, uint64_t off, uint64_t n,

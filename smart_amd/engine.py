@@ -64,6 +64,7 @@ def lib():
         "smartgpu_stream_mark": (i32, [i32, i32]),
         "smartgpu_stream_elapsed_ms": (i32, [i32, C.POINTER(C.c_double)]),
         "smartgpu_stream_handle": (vp, [i32]),
+        "smartgpu_tune": (i32, [i32, i32]),
     }
     for a in ALGOS:
         sig["smartgpu_%s_search" % a] = (i32, [vp, i32, vp, i32])
@@ -242,6 +243,11 @@ def stream_elapsed_ms(device):
     if lib().smartgpu_stream_elapsed_ms(device, C.byref(ms)) != 0:
         raise _err("stream_elapsed_ms")
     return float(ms.value)
+
+
+def tune(key, value):
+    if lib().smartgpu_tune(key, value) != 0:
+        raise _err("tune")
 
 
 def build_table(which, P):

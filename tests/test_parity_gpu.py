@@ -44,6 +44,30 @@ def test_fuzz_vectors(oracle):
             assert got[a] == r["count"], (a, r, got)
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_horspool_variants(oracle, variant):
+    """All Horspool regimes (flat LDS tile / bank-private layout / packed) on the fuzz
+    vectors, the dense small-alphabet case and sub-ranges."""
+    from smart_amd import engine
+    engine.tune(0, variant)
+    try:
+        for r in load_golden("fuzz_vectors.json")["rows"]:
+            P, T = fuzz_case(oracle, r)
+            text = Text.upload(T)
+            got = smart_amd.search("hor", P, text)[0]
+            text.free()
+            assert got == r["count"], (variant, r, got)
+        T = oracle.gen_text(77, 2, 0, 1_500_000)
+        text = Text.upload(T)
+        for m in (1, 2, 3, 4, 7, 8, 15, 16, 33, 100, 255):
+            P = T[4321:4321 + m]
+            assert smart_amd.search("hor", P, text)[0] == oracle.search("epsm", P, T), (variant, m)
+            off, n = 70001, 999999
+            assert smart_amd.search("hor", P, text, off=off, n=n)[0] == oracle.search("epsm", P, T[off:off + n]), (variant, m)
+    finally:
+        engine.tune(0, 0)
+
+
 def test_survey_vectors(oracle):
     g = load_golden("survey_vectors.json")
     texts = {}
@@ -173,7 +197,7 @@ def test_plan_slots_and_timing(oracle):
         c, ms = p.result(i)
         assert c == oracle.search("hor", pats[i], T)
         assert ms > 0
-    assert plans[0].kernel_name == "hor_scan"
+    assert plans[0].kernel_name == "hor_scan"  # m=32: flat-tile regime
 
 
 def test_full_size_properties(oracle):

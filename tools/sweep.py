@@ -31,7 +31,11 @@ def main():
     ap.add_argument("--algos", default=",".join(smart_amd.ALGOS))
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--tune", default="", help="comma list key=value passed to smartgpu_tune")
     args = ap.parse_args()
+    for kv in filter(None, args.tune.split(",")):
+        k, v = kv.split("=")
+        smart_amd.engine.tune(int(k), int(v))
     n = int(args.gib * (1 << 30))
     text = Text.generate(SEED, args.sigma, n)
     rows = []
