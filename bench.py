@@ -91,9 +91,9 @@ def main():
     total_n = shard * world
     # rank r owns start positions [r*shard, (r+1)*shard) (the last rank stops at
     # total_n - m); it holds m-1 extra bytes so those windows are complete
-    last = rank == world - 1
-    local_len = shard if last else shard + m - 1
-    text = Text.generate(SEED, args.sigma, local_len, off=rank * shard, device=local_rank)
+    from smart_amd.sharding import weak_shard
+    global_off, local_len = weak_shard(shard, m, rank, world)
+    text = Text.generate(SEED, args.sigma, local_len, off=global_off, device=local_rank)
 
     # patterns: cut from the GLOBAL text at seeded offsets (any shard)
     def pattern(j):

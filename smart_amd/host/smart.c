@@ -1,0 +1,466 @@
+/*
+ * smart — benchmark driver for the MI355X exact-matching engine.
+ *
+ * Restates the behaviour of SMART's driver (reference: src/smart.c) on top of
+ * the C ABI in include/smartgpu.h: same flags, same experiment loop, same
+ * stdout report and TXT table.  What changes is the plumbing underneath:
+ *   - the text lives in HBM (smartgpu_text_*) instead of a SysV segment
+ *     (smart.c:553-568) and is loaded once per corpus (getText, smart.c:95-138);
+ *   - an algorithm is an in-process call (smartgpu_search64) instead of
+ *     system("./source/bin/<algo> shared ...") (smart.c:140-146);
+ *   - pre/search times come back as out-parameters instead of two 8-byte shm
+ *     segments (main.h:28-37).
+ * Additions: -algo LIST, -data DIR, -gpu D, -gen (device-generated rand corpora
+ * when the data directory has none), a GB/s column.
+ *
+ * Build: make -C smart_amd/host   (gcc, links ../csrc/libsmartgpu.so)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <time.h>
+
+#include "smartgpu.h"
+
+#define XSIZE SMARTGPU_XSIZE
+#define MAX_ALGOS SMARTGPU_NUM_ALGOS
+#define MAX_LENGTHS 17
+#define MAX_CORPORA 15
+#define MAX_RUNS 5000 /* -pset upper bound (smart.c:183 has STDTIME[5000]) */
+
+/* pattern-length sets (reference: src/sets.h:23-25) */
+static const int LEN_VERY_SHORT[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 0};
+static const int LEN_SHORT[] = {2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32, 0};
+static const int LEN_LARGE[] = {2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 0};
+
+/* corpus names and alphabet sizes (reference: src/sets.h:26-27) */
+static const char *CORPUS[MAX_CORPORA] = {"rand2", "rand4", "rand8", "rand16", "rand32", "rand64", "rand128",
+                                          "rand250", "italianTexts", "englishTexts", "frenchTexts",
+                                          "chineseTexts", "midimusic", "genome", "protein"};
+static const int CORPUS_SIGMA[MAX_CORPORA] = {2, 4, 8, 16, 32, 64, 128, 250, 128, 128, 128, 128, 128, 64, 64};
+
+/* per-search status, as the reference harness records it (smart.c:143-145,330-343) */
+enum { ST_OK = 1, ST_ERROR = 0, ST_NA = -1, ST_OUT = -2 };
+
+struct options {
+    int runs;          /* -pset  (smart.c:415 VOLTE = 500) */
+    long tsize;        /* -tsize in bytes (smart.c:416: 1 MiB) */
+    int minlen, maxlen;
+    const int *lengths;
+    int occ, pre, dif, std, txt;
+    int limit_ms;      /* -tb (smart.c:424: 300 ms) */
+    int device;
+    const char *data_dir;
+    char text_arg[256];
+    char simple_p[128], simple_t[1100];
+    int simple;
+    int algos[MAX_ALGOS], nalgos;
+};
+
+static void usage(void)
+{
+    printf("\tThis is a basic help guide for using the tool\n\n");
+    printf("\t-pset N       computes running times as the mean of N runs (default 500)\n");
+    printf("\t-tsize S      set the upper bound dimension (in Mb) of the text used for experimental results (default 1Mb)\n");
+    printf("\t-plen L U     test only patterns with a length between L and U (included).\n");
+    printf("\t-text F       performs experimental results using text buffer F (mandatory unless you use the -simple parameter)\n");
+    printf("\t              Use option \"all\" to performe experimental results using all text buffers.\n");
+    printf("\t              Use the style A-B-C to performe experimental results using multiple text buffers.\n");
+    printf("\t-short        computes experimental results using short length patterns (from 2 to 32)\n");
+    printf("\t-vshort       computes experimental results using very short length patterns (from 1 to 16)\n");
+    printf("\t-occ          prints the average number of occurrences\n");
+    printf("\t-pre          computes separately preprocessing times and searching times\n");
+    printf("\t-tb L         set to L the upper bound for any wort case running time (in ms). The default value is 300 ms\n");
+    printf("\t-dif          prints the number the best and the worst running time\n");
+    printf("\t-std          prints the standard deviations of the running times\n");
+    printf("\t-txt          output results in txt tabular format\n");
+    printf("\t-simple P T   executes a single run searching T (max 1000 chars) for occurrences of P (max 100 chars)\n");
+    printf("\t-algo LIST    comma separated algorithms out of hor,bm,kmp,so,bndm,epsm (default: all six,\n");
+    printf("\t              or the ones marked #1 in source/algorithms.h when that file exists)\n");
+    printf("\t-data DIR     directory holding <corpus>/index.txt (default \"data\")\n");
+    printf("\t-gpu D        device ordinal (default 0)\n");
+    printf("\t-h            gives this help list\n\n");
+}
+
+static int is_number(const char *s)
+{
+    if (!*s) return 0;
+    for (; *s; ++s)
+        if (*s < '0' || *s > '9') return 0;
+    return 1;
+}
+
+static void upper(char *dst, const char *src)
+{
+    for (; *src; ++src, ++dst) *dst = (*src >= 'a' && *src <= 'z') ? (char)(*src - 'a' + 'A') : *src;
+    *dst = 0;
+}
+
+/* registry in SMART's format: one "#<0|1> #<name> " entry per algorithm
+ * (reference: getAlgo, src/function.h:62-77).  Returns the number selected,
+ * -1 when the file is absent. */
+static int read_registry(const char *path, int *sel)
+{
+    FILE *fp = fopen(path, "r");
+    if (!fp) return -1;
+    int c, n = 0;
+    while ((c = getc(fp)) != EOF) {
+        if (c != '#') continue;
+        int flag = getc(fp) - '0';
+        getc(fp);
+        getc(fp); /* " #" */
+        char name[32];
+        int j = 0;
+        while ((c = getc(fp)) != EOF && c != ' ' && c != '\n' && j < 31) name[j++] = (char)c;
+        name[j] = 0;
+        int id = smartgpu_algo_id(name);
+        if (flag == 1 && id >= 0) sel[n++] = id;
+    }
+    fclose(fp);
+    return n;
+}
+
+static int sigma_of(const char *corpus)
+{
+    for (int i = 0; i < MAX_CORPORA; ++i)
+        if (!strcmp(CORPUS[i], corpus)) return CORPUS_SIGMA[i];
+    return 0;
+}
+
+/* Load up to `cap` bytes of the files listed as #name# in <dir>/<corpus>/index.txt
+ * (reference: getText, src/smart.c:95-138).  Returns the byte count, -1 if there
+ * is no index file. */
+static long load_corpus(const char *dir, const char *corpus, unsigned char *T, long cap)
+{
+    char path[600];
+    snprintf(path, sizeof path, "%s/%s/index.txt", dir, corpus);
+    FILE *index = fopen(path, "r");
+    if (!index) return -1;
+    long n = 0;
+    int c;
+    while (n < cap && (c = getc(index)) != EOF) {
+        if (c != '#') continue;
+        char name[300];
+        int j = 0;
+        while ((c = getc(index)) != EOF && c != '#' && j < 299) name[j++] = (char)c;
+        name[j] = 0;
+        snprintf(path, sizeof path, "%s/%s/%s", dir, corpus, name);
+        printf("\tLoading the file %s\n", path);
+        FILE *in = fopen(path, "r");
+        if (!in) {
+            printf("\tError in loading text file %s\n", path);
+            continue;
+        }
+        n += (long)fread(T + n, 1, (size_t)(cap - n), in);
+        fclose(in);
+    }
+    fclose(index);
+    return n;
+}
+
+static void alphabet_report(const unsigned char *T, long n)
+{
+    int seen[256] = {0}, nalpha = 0, maxcode = 0;
+    for (long i = 0; i < n; ++i) {
+        if (!seen[T[i]]++) nalpha++;
+        if (T[i] > maxcode) maxcode = T[i];
+    }
+    printf("\tAlphabet of %d characters.\n", nalpha);
+    printf("\tGreater chararacter has code %d.\n", maxcode);
+}
+
+static void top_edge(void)
+{
+    printf("\t");
+    for (int i = 0; i < 60; ++i) putchar('_');
+    printf("\n");
+}
+
+struct cell { double mean, pre, best, worst, std, gbs; int status; };
+
+/* One corpus: every pattern length x every algorithm x `runs` patterns
+ * (reference: run_setting, src/smart.c:178-402). */
+static void run_corpus(const struct options *o, const char *corpus, const unsigned char *T, long n,
+                       smartgpu_text *text, const char *code, struct cell table[MAX_ALGOS][MAX_LENGTHS])
+{
+    unsigned char **pats = malloc(sizeof(*pats) * (size_t)o->runs);
+    for (int i = 0; i < o->runs; ++i) pats[i] = malloc(XSIZE + 1);
+    double *sample = malloc(sizeof(double) * (size_t)(o->runs + 1));
+
+    for (int il = 0; o->lengths[il] > 0; ++il) {
+        const int m = o->lengths[il];
+        if (m < o->minlen || m > o->maxlen) continue;
+        if (!o->simple && m >= n) continue;
+        /* patterns are cut from the text at random offsets (smart.c:148-158) */
+        for (int i = 0; i < o->runs; ++i) {
+            if (o->simple) {
+                memcpy(pats[i], o->simple_p, (size_t)m);
+            } else {
+                long k = random() % (n - m);
+                memcpy(pats[i], T + k, (size_t)m);
+            }
+            pats[i][m] = 0;
+        }
+        printf("\n");
+        top_edge();
+        if (!o->simple) printf("\tExperimental results on %s: %s\n", corpus, code);
+        else printf("\tExperimental results on %s\n", (const char *)T);
+        printf("\tSearching for a set of %d patterns with length %d\n", o->runs, m);
+        printf("\tTesting %d algorithms\n\n", o->nalgos);
+
+        for (int ia = 0; ia < o->nalgos; ++ia) {
+            const int algo = o->algos[ia];
+            char name[32], head[64];
+            upper(name, smartgpu_algo_name(algo));
+            snprintf(head, sizeof head, "\t - [%d/%d] %s ", ia + 1, o->nalgos, name);
+            printf("%s", head);
+            for (size_t i = strlen(head); i < 35; ++i) putchar('.');
+            fflush(stdout);
+
+            struct cell *c = &table[ia][il];
+            memset(c, 0, sizeof *c);
+            c->best = 999.0;
+            long long total_occ = 0;
+            int status = ST_OK;
+            for (int k = 1; k <= o->runs; ++k) {
+                int perc = (100 * k) / o->runs;
+                printf(perc < 10 ? "\b\b\b\b[%d%%]" : perc < 100 ? "\b\b\b\b\b[%d%%]" : "\b\b\b\b[%d%%]", perc);
+                fflush(stdout);
+                uint64_t count = 0;
+                double pre_ms = 0, run_ms = 0;
+                int rc = smartgpu_search64(algo, pats[k - 1], (uint32_t)m, text, 0, (uint64_t)n, &count, &pre_ms, &run_ms);
+                long long occur = rc == SMARTGPU_OK ? (long long)count : -1;
+                double e = o->pre ? run_ms : run_ms + pre_ms; /* smart.c:323 */
+                sample[k] = e;
+                c->mean += e;
+                c->pre += pre_ms;
+                if (e < c->best) c->best = e;
+                if (e > c->worst) c->worst = e;
+                total_occ += occur;
+                if (occur <= 0 && !o->simple) { /* smart.c:330-336 */
+                    status = occur == 0 ? ST_ERROR : ST_NA;
+                    break;
+                }
+                if (e > o->limit_ms) { /* smart.c:337-343 */
+                    status = ST_OUT;
+                    break;
+                }
+            }
+            if (status != ST_OK) {
+                c->mean = c->pre = 0;
+            } else {
+                c->mean /= o->runs;
+                c->pre /= o->runs;
+                for (int k = 1; k <= o->runs; ++k) c->std += (sample[k] - c->mean) * (sample[k] - c->mean);
+                c->std = sqrt(c->std / o->runs); /* population std, smart.c:349-351 */
+                c->gbs = c->mean > 0 ? (double)n / (c->mean * 1e-3) / 1e9 : 0;
+            }
+            c->status = status;
+            if (status == ST_OK) {
+                char data[64];
+                printf("\b\b\b\b\b\b\b.[OK]  ");
+                if (o->pre) snprintf(data, sizeof data, "\t%.2f + %.2f ms", c->pre, c->mean);
+                else snprintf(data, sizeof data, "\t%.2f ms", c->mean);
+                printf("%s", data);
+                for (size_t i = strlen(data); i < 20; ++i) putchar(' ');
+                if (o->dif) {
+                    snprintf(data, sizeof data, " [%.2f, %.2f]", c->best, c->worst);
+                    printf("%s", data);
+                    for (size_t i = strlen(data); i < 20; ++i) putchar(' ');
+                }
+                if (o->std) {
+                    snprintf(data, sizeof data, " std %.2f", c->std);
+                    printf("%s", data);
+                    for (size_t i = strlen(data); i < 15; ++i) putchar(' ');
+                }
+                if (o->occ) printf("\tocc %lld", total_occ / o->runs);
+                printf("\t%.1f GB/s", c->gbs);
+                printf("\n");
+            } else if (status == ST_ERROR) {
+                printf("\b\b\b\b\b\b\b\b.[ERROR] \n");
+            } else if (status == ST_NA) {
+                printf("\b\b\b\b\b.[--]  \n");
+                fprintf(stderr, "%s m=%d: %s\n", name, m, smartgpu_last_error());
+            } else {
+                printf("\b\b\b\b\b\b.[OUT]  \n");
+            }
+        }
+    }
+    printf("\n");
+    top_edge();
+    for (int i = 0; i < o->runs; ++i) free(pats[i]);
+    free(pats);
+    free(sample);
+}
+
+/* results/<code>/<corpus>.txt: one row per algorithm, one column per length
+ * (reference: outputTXT, src/output.h:116-151) */
+static void write_txt(const struct options *o, const char *corpus, const char *code,
+                      struct cell table[MAX_ALGOS][MAX_LENGTHS])
+{
+    char path[400];
+    mkdir("results", 0775);
+    snprintf(path, sizeof path, "results/%s", code);
+    mkdir(path, 0775);
+    snprintf(path, sizeof path, "results/%s/%s.txt", code, corpus);
+    FILE *fp = fopen(path, "w");
+    if (!fp) return;
+    for (int ia = 0; ia < o->nalgos; ++ia) {
+        char name[32];
+        upper(name, smartgpu_algo_name(o->algos[ia]));
+        fprintf(fp, "%-20s", name);
+        for (int il = 0; o->lengths[il] > 0; ++il) {
+            int m = o->lengths[il];
+            if (m < o->minlen || m > o->maxlen) continue;
+            if (table[ia][il].mean > 0) fprintf(fp, "\t%.2f", table[ia][il].mean);
+            else fprintf(fp, "\t-");
+        }
+        fprintf(fp, "\n");
+    }
+    fclose(fp);
+    printf("\tOUTPUT RUNNING TIMES %s (results/%s/%s.txt)\n", code, code, corpus);
+}
+
+int main(int argc, char **argv)
+{
+    struct options o;
+    memset(&o, 0, sizeof o);
+    o.runs = 500;
+    o.tsize = 1048576;
+    o.minlen = 1;
+    o.maxlen = XSIZE;
+    o.lengths = LEN_LARGE;
+    o.limit_ms = 300;
+    o.data_dir = "data";
+    int custom_len[2] = {0, 0};
+
+    if (argc == 1) { printf("No parameter given. Use -h for help.\n\n"); return 0; }
+    const char *bad = "Error in input parameters. Use -h for help.\n\n";
+    for (int i = 1; i < argc; ++i) {
+        const char *a = argv[i];
+        int has1 = i + 1 < argc, has2 = i + 2 < argc;
+        if (!strcmp(a, "-h")) { usage(); return 0; }
+        else if (!strcmp(a, "-pset")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.runs = atoi(argv[++i]); }
+        else if (!strcmp(a, "-tsize")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.tsize = atol(argv[++i]) * 1048576L; }
+        else if (!strcmp(a, "-tb")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.limit_ms = atoi(argv[++i]); }
+        else if (!strcmp(a, "-text")) { if (!has1) { printf("%s", bad); return 0; } snprintf(o.text_arg, sizeof o.text_arg, "%s", argv[++i]); }
+        else if (!strcmp(a, "-plen")) {
+            if (!has2 || !is_number(argv[i + 1]) || !is_number(argv[i + 2])) { printf("%s", bad); return 0; }
+            o.minlen = atoi(argv[++i]);
+            o.maxlen = atoi(argv[++i]);
+            if (o.minlen < 1 || o.minlen > XSIZE) { printf("Error in input parameters. The minimum length is not a valid argument.\n\n"); return 0; }
+            if (o.maxlen < 1 || o.minlen > o.maxlen) { printf("Error in input parameters. The maximum length is not a valid argument.\n\n"); return 0; }
+        }
+        else if (!strcmp(a, "-simple")) {
+            if (!has2) { printf("%s", bad); return 0; }
+            if (strlen(argv[i + 1]) > 100) { printf("Error in input parameters. Max 100 chars for P parameter.\n\n"); return 0; }
+            if (strlen(argv[i + 2]) > 1000) { printf("Error in input parameters. Max 1000 chars for T parameter.\n\n"); return 0; }
+            strcpy(o.simple_p, argv[++i]);
+            strcpy(o.simple_t, argv[++i]);
+            o.simple = 1;
+        }
+        else if (!strcmp(a, "-occ")) o.occ = 1;
+        else if (!strcmp(a, "-pre")) o.pre = 1;
+        else if (!strcmp(a, "-dif")) o.dif = 1;
+        else if (!strcmp(a, "-std")) o.std = 1;
+        else if (!strcmp(a, "-txt")) o.txt = 1;
+        else if (!strcmp(a, "-tex") || !strcmp(a, "-php")) { /* report writers outside the hot path */ }
+        else if (!strcmp(a, "-short")) o.lengths = LEN_SHORT;
+        else if (!strcmp(a, "-vshort")) o.lengths = LEN_VERY_SHORT;
+        else if (!strcmp(a, "-data")) { if (!has1) { printf("%s", bad); return 0; } o.data_dir = argv[++i]; }
+        else if (!strcmp(a, "-gpu")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.device = atoi(argv[++i]); }
+        else if (!strcmp(a, "-algo")) {
+            if (!has1) { printf("%s", bad); return 0; }
+            char list[256];
+            snprintf(list, sizeof list, "%s", argv[++i]);
+            for (char *tok = strtok(list, ","); tok; tok = strtok(NULL, ",")) {
+                int id = smartgpu_algo_id(tok);
+                if (id < 0) { printf("Error in input parameters. Unknown algorithm %s.\n\n", tok); return 0; }
+                if (o.nalgos < MAX_ALGOS) o.algos[o.nalgos++] = id;
+            }
+        }
+        else { printf("%s", bad); return 0; }
+    }
+    if (o.runs < 1 || o.runs > MAX_RUNS) { printf("%s", bad); return 0; }
+    if (o.text_arg[0] && o.simple) { printf("Error in input parameters. Both parameters -simple and -text defined.\n\n"); return 0; }
+    if (!o.text_arg[0] && !o.simple) { printf("Error in input parameters. No filename given.\n\n"); return 0; }
+    if (o.nalgos == 0) {
+        int n = read_registry("source/algorithms.h", o.algos);
+        if (n > 0) o.nalgos = n;
+        else for (int i = 0; i < MAX_ALGOS; ++i) o.algos[o.nalgos++] = i;
+    }
+    if (smartgpu_device_count() <= o.device) {
+        fprintf(stderr, "smart: no usable GPU %d: %s\n", o.device, smartgpu_last_error());
+        return 1;
+    }
+    srandom((unsigned)time(NULL));
+    char code[64];
+    snprintf(code, sizeof code, "EXP%d", (int)time(NULL));
+    static struct cell table[MAX_ALGOS][MAX_LENGTHS];
+
+    if (o.simple) { /* smart.c:570-596 */
+        long n = (long)strlen(o.simple_t);
+        int m = (int)strlen(o.simple_p);
+        custom_len[0] = m;
+        o.lengths = custom_len;
+        printf("\n\tText of %ld chars : %s\n", n, o.simple_t);
+        printf("\tPattern of %d chars : %s\n", m, o.simple_p);
+        printf("\tStarting experimental tests with code %s\n", code);
+        smartgpu_text *text = smartgpu_text_upload(o.simple_t, (uint64_t)n, o.device);
+        if (!text) { fprintf(stderr, "smart: %s\n", smartgpu_last_error()); return 1; }
+        run_corpus(&o, "", (const unsigned char *)o.simple_t, n, text, code, table);
+        smartgpu_text_free(text);
+        return 0;
+    }
+
+    /* corpus list: "all" or A-B-C (smart.c:597-667, split_filelsit function.h:112-129) */
+    const char *names[MAX_CORPORA];
+    int ncorp = 0;
+    char list[256];
+    snprintf(list, sizeof list, "%s", o.text_arg);
+    if (!strcmp(list, "all")) {
+        for (int i = 0; i < MAX_CORPORA; ++i) names[ncorp++] = CORPUS[i];
+    } else {
+        for (char *tok = strtok(list, "-"); tok && ncorp < MAX_CORPORA; tok = strtok(NULL, "-")) names[ncorp++] = tok;
+    }
+    printf("\tStarting experimental tests with code %s\n", code);
+    unsigned char *T = malloc((size_t)o.tsize + 16);
+    for (int ic = 0; ic < ncorp; ++ic) {
+        const char *corpus = names[ic];
+        printf("\n\tTry to process archive (%d/%d) %s\n", ic + 1, ncorp, corpus);
+        int sigma = sigma_of(corpus);
+        if (!sigma) { printf("\tError in loading alphabet size\n"); continue; }
+        smartgpu_text *text = NULL;
+        long n = load_corpus(o.data_dir, corpus, T, o.tsize);
+        if (n > 0) {
+            T[n] = 0;
+            text = smartgpu_text_upload(T, (uint64_t)n, o.device);
+        } else if (!strncmp(corpus, "rand", 4)) {
+            /* no corpus file: generate rand<sigma> on the device and read it
+             * back once for pattern extraction */
+            n = o.tsize;
+            printf("\tNo index file under %s/%s: generating %ld bytes of rand%d on the device\n", o.data_dir, corpus, n, sigma);
+            text = smartgpu_text_generate(0x5EED0001ull, sigma, 0, (uint64_t)n, o.device);
+            if (text && smartgpu_text_read(text, 0, (uint64_t)n, T) != SMARTGPU_OK) { smartgpu_text_free(text); text = NULL; }
+        } else {
+            printf("\tError in loading text buffer. No index file exists.\n");
+            continue;
+        }
+        if (!text) { fprintf(stderr, "smart: %s\n", smartgpu_last_error()); continue; }
+        alphabet_report(T, n);
+        printf("\tText buffer of dimension %ld byte\n", n);
+        time_t now = time(NULL);
+        char stamp[32];
+        strftime(stamp, sizeof stamp, "%Y:%m:%d %H:%M:%S", localtime(&now));
+        printf("\tExperimental tests started on %s\n", stamp);
+        memset(table, 0, sizeof table);
+        run_corpus(&o, corpus, T, n, text, code, table);
+        if (o.txt) write_txt(&o, corpus, code, table);
+        smartgpu_text_free(text);
+    }
+    free(T);
+    return 0;
+}

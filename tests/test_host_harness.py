@@ -1,0 +1,66 @@
+"""The C harness (smart_amd/host): argument handling on CPU, full runs on GPU."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+BIN = os.path.join(ROOT, "smart_amd", "bin")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "smart_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "smart_amd", "host")])
+
+
+def run(*args, cwd=None):
+    return subprocess.run([os.path.join(BIN, args[0])] + list(args[1:]), capture_output=True, text=True,
+                          cwd=cwd or ROOT, timeout=600)
+
+
+def test_smart_argument_errors_match_reference_messages():
+    # messages of src/smart.c:438-548
+    assert "No parameter given. Use -h for help." in run("smart").stdout
+    assert "-pset N" in run("smart", "-h").stdout
+    assert "Error in input parameters. Use -h for help." in run("smart", "-bogus").stdout
+    assert "Error in input parameters. Use -h for help." in run("smart", "-pset", "abc").stdout
+    assert "The minimum length is not a valid argument" in run("smart", "-plen", "0", "5").stdout
+    assert "The maximum length is not a valid argument" in run("smart", "-plen", "9", "5").stdout
+    assert "Both parameters -simple and -text defined" in run("smart", "-simple", "ab", "abab", "-text", "rand2").stdout
+    assert "No filename given" in run("smart", "-occ").stdout
+    assert "Unknown algorithm" in run("smart", "-algo", "nope", "-text", "rand2").stdout
+
+
+def test_test_tool_usage():
+    assert "usage: ./test ALGONAME" in run("test").stdout
+    assert run("test", "nope").returncode == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["hor", "bm", "kmp", "so", "bndm", "epsm"])
+def test_reference_cases_through_plugin_shape(algo):
+    r = run("test", algo)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Well done! Test passed successfully" in r.stdout
+
+
+@pytest.mark.gpu
+def test_smart_report_lines(tmp_path):
+    r = run("smart", "-text", "rand128", "-plen", "32", "32", "-pset", "5", "-occ", "-pre", "-dif", "-std", "-txt",
+            cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert "Searching for a set of 5 patterns with length 32" in out
+    assert "Testing 6 algorithms" in out
+    for name in ("HOR", "BM", "KMP", "SO", "BNDM", "EPSM"):
+        line = [ln for ln in out.splitlines() if re.search(r"\] %s \." % name, ln)]
+        assert line and "[OK]" in line[0] and "occ 1" in line[0] and "GB/s" in line[0], (name, out)
+        assert re.search(r"\d+\.\d\d \+ \d+\.\d\d ms", line[0])
+    table = list((tmp_path / "results").glob("EXP*/rand128.txt"))
+    assert table and table[0].read_text().startswith("HOR")
+    # -simple: the reference's own example (SURVEY.md §5 hazard 3 segfaults EPSM there)
+    r = run("smart", "-simple", "aba", "ababababab", "-pset", "1", "-occ", cwd=str(tmp_path))
+    assert r.stdout.count("occ 4") == 6, r.stdout
