@@ -406,57 +406,108 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
 
 // ---------------------------------------------------------------------------
 // Shift-Or, 32-bit words like the reference  (src/algos/so.c:27-96)
-// Tiles indexed by START position; lane scans bytes [a, b+w-1) with D = ~0 at a.
-// L/16 is odd so the lanes' 16-byte LDS reads fall in distinct bank groups.
-// LDS: u32 S[256] | text [tile0, tile0+TB+32)
+// Tiles indexed by START position; a lane scans bytes [a, b+w-1) with the state
+// all-ones at a (w = min(m,32)).  L/16 is odd so the lanes' 16-byte LDS reads
+// fall in distinct bank groups.  LDS: u32 S'[257] | text [tile0, tile0+TB+32)
+//
+// The state is kept left-aligned: D' = D << (32-w) and S'[c] = S[c] << (32-w),
+// so the recurrence is unchanged (D' = (D' << 1) | S'[c], so.c:55) and the hit
+// test "D < lim" (so.c:56: bit w-1 of D clear) is the sign test D' >= 0.
+// S'[256] = ~0 << (32-w) is the entry bytes outside the lane's range are mapped
+// to: it keeps the state all-ones, i.e. "not started yet" / "no hit".
+// Per 16-byte chunk the 16 table gathers are issued together (they do not
+// depend on the state), then the recurrence runs on registers.
 // ---------------------------------------------------------------------------
-template <int THREADS, int L>
+template <int THREADS, int L, bool LONG>  // LONG: m > 32, prefix hits are verified
 __global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a, uint64_t tile_first,
                                                    uint32_t ntiles)
 {
     constexpr int TB = THREADS * L;
     static_assert((L / 16) % 2 == 1, "L/16 must be odd (LDS bank spread)");
+    static_assert(L % 16 == 0 && TB % (THREADS * 16) == 0, "whole 16-byte rows");
+    constexpr int N = TB / (THREADS * 16);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32;
-    const uint32_t hibit = 1u << (w - 1);
-    uint32_t* S = reinterpret_cast<uint32_t*>(smem);
-    uint8_t* txt = smem + 1024;
+    uint32_t* S = reinterpret_cast<uint32_t*>(smem);  // 257 entries, padded to 1040 B
+    uint8_t* txt = smem + 1040;
 
-    for (uint32_t i = threadIdx.x; i < 256; i += THREADS)
-        S[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i];
+    for (uint32_t i = threadIdx.x; i < 257; i += THREADS)
+        S[i] = (i < 256 ? reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] : 0xFFFFFFFFu)
+               << (32 - w);  // low 32-w bits stay zero, so nothing shifts up into the state
 
     uint32_t hits = 0;
-    for (uint64_t t = tile_first + blockIdx.x; t < tile_first + ntiles; t += gridDim.x) {
+    const uint64_t t_end = tile_first + ntiles;
+    static_assert(N == 5, "prefetch registers are written out for L = 80");
+    uint4 p0, p1, p2, p3, p4, ph;  // prefetch registers: 5 tile rows + 32 bytes of forward halo
+    const bool halo_lane = threadIdx.x < 2;
+    auto issue = [&](uint64_t tile0) {
+        const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
+        p0 = *reinterpret_cast<const uint4*>(src);
+        p1 = *reinterpret_cast<const uint4*>(src + THREADS * 16);
+        p2 = *reinterpret_cast<const uint4*>(src + THREADS * 32);
+        p3 = *reinterpret_cast<const uint4*>(src + THREADS * 48);
+        p4 = *reinterpret_cast<const uint4*>(src + THREADS * 64);
+        if (halo_lane) ph = *reinterpret_cast<const uint4*>(src + TB);
+    };
+    uint64_t t = tile_first + blockIdx.x;
+    issue(t * TB);
+    for (; t < t_end; t += gridDim.x) {
         const uint64_t tile0 = t * TB;
         __syncthreads();
-        stage_tile<THREADS, TB>(txt, a.text + tile0);
-        stage_bytes<THREADS>(txt + TB, a.text + tile0 + TB, 32);
+        {
+            uint8_t* dst = txt + threadIdx.x * 16u;
+            *reinterpret_cast<uint4*>(dst) = p0;
+            *reinterpret_cast<uint4*>(dst + THREADS * 16) = p1;
+            *reinterpret_cast<uint4*>(dst + THREADS * 32) = p2;
+            *reinterpret_cast<uint4*>(dst + THREADS * 48) = p3;
+            *reinterpret_cast<uint4*>(dst + THREADS * 64) = p4;
+            if (halo_lane) *reinterpret_cast<uint4*>(dst + TB) = ph;
+        }
         __syncthreads();
+        if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
+
         const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
         const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
         const uint64_t sb = seg + L < a.s_end ? seg + L : a.s_end;
         if (sa < sb) {
             const uint32_t j0 = (uint32_t)(sa - tile0);
             const uint32_t jend = (uint32_t)(sb - tile0) + w - 1;
-            uint32_t D = 0xFFFFFFFFu;
+            uint32_t D = 0xFFFFFFFFu << (32 - w);
             for (uint32_t base = j0 & ~15u; base < jend; base += 16) {
                 const uint4 v = *reinterpret_cast<const uint4*>(txt + base);
                 const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+                // bytes of this chunk inside [j0, jend): all of them except at the two ends
+                const bool full = base >= j0 && base + 16 <= jend;
+                uint32_t sv[16];
+                if (full) {
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const uint32_t j = base + q;
-                    const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
-                    const bool live = (j >= j0) & (j < jend);
-                    if (live) {
-                        D = (D << 1) | S[c];  // so.c:55
-                        if (!(D & hibit)) {   // so.c:56  (D < lim)
-                            if (w == m) {
-                                ++hits;
-                            } else {
-                                const uint64_t h = tile0 + j - (w - 1);
-                                hits += global_equal(a.text + h + w, a.blob + w, m - w);
-                            }
-                        }
+                    for (int q = 0; q < 16; ++q) sv[q] = S[(d[q >> 2] >> (8 * (q & 3))) & 0xFFu];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const uint32_t j = base + q;
+                        const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+                        sv[q] = S[(j >= j0 && j < jend) ? c : 256u];
+                    }
+                }
+                if (!LONG) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        D = (D << 1) | sv[q];      // so.c:55
+                        hits += (int32_t)D >= 0;  // so.c:56
+                    }
+                } else {
+                    uint32_t hm = 0;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        D = (D << 1) | sv[q];
+                        hm |= ((int32_t)D >= 0) ? (1u << q) : 0u;
+                    }
+                    while (hm) {  // 32-byte prefix matched at tile0+base+q-31: verify P[32..m)
+                        const uint32_t q = __builtin_ctz(hm);
+                        hm &= hm - 1;
+                        const uint64_t h = tile0 + base + q - (w - 1);
+                        hits += global_equal(a.text + h + w, a.blob + w, m - w);
                     }
                 }
             }
@@ -467,64 +518,87 @@ __global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a, uint64_t tile_fir
 
 // ---------------------------------------------------------------------------
 // Knuth-Morris-Pratt  (reference: src/algos/kmp.c:27-68)
-// Lane restarts in state 0 at its first start position and scans m-1 bytes
-// into the next lane's run.  LDS: pattern | i16 next[m+1] | text [tile0, tile0+TB+halo)
+//
+// The automaton is serial per lane, so the text is NOT staged through LDS: each
+// lane streams its own run of `seg_len` start positions straight from HBM/L2,
+// 16 bytes per load with the next chunk prefetched, restarts in state 0 at its
+// first start position and scans m-1 bytes into the next lane's run (SURVEY.md
+// §7 restart table).  seg_len is chosen on the host (>= 2(m-1), so the re-scan
+// is bounded, and small enough to keep every SIMD populated).  A lane's 128-B
+// line is consumed over 8 consecutive loads and stays in L2 meanwhile; the
+// kernel is bound by the per-byte dependency chain, not by memory.
+// LDS holds only the tables: pattern | i16 next[m+1].
+// State 0 (by far the most common on large alphabets) is handled in registers:
+// next[0] = -1, so the step is st = (c == P[0]) (kmp.c:57-60).
 // ---------------------------------------------------------------------------
-template <int THREADS, int L>
-__global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a, uint64_t tile_first,
-                                                    uint32_t ntiles)
+template <bool CHECK>
+__device__ __forceinline__ void kmp_chunk(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
+                                          int& st, uint32_t& hits, int m, uint32_t p0,
+                                          const uint8_t* __restrict__ pat,
+                                          const int16_t* __restrict__ next)
 {
-    constexpr int TB = THREADS * L;
-    static_assert((L / 16) % 2 == 1, "L/16 must be odd (LDS bank spread)");
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+        if (CHECK) {
+            const uint32_t j = j_base + q;
+            if (j < j0 || j >= jend) continue;
+        }
+        if (st == 0) {
+            st = (c == p0) ? 1 : 0;
+        } else {
+            while (st >= 0 && pat[st] != c) st = next[st];
+            ++st;
+        }
+        if (st >= m) {  // kmp.c:61-64
+            ++hits;
+            st = next[m];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void kmp_scan(ScanArgs a, uint32_t seg_len, uint64_t nsegs)
+{
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int m = (int)a.m;
-    const uint32_t FH16 = round16(a.halo);  // forward halo, a.halo = m-1
     uint8_t* pat = smem;
     int16_t* next = reinterpret_cast<int16_t*>(smem + round16(m));
-    uint8_t* txt = smem + round16(m) + round16(2 * (m + 1));
-
-    for (uint32_t i = threadIdx.x; i < (uint32_t)m; i += THREADS) pat[i] = a.blob[i];
-    for (uint32_t i = threadIdx.x; i <= (uint32_t)m; i += THREADS)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)m; i += 256) pat[i] = a.blob[i];
+    for (uint32_t i = threadIdx.x; i <= (uint32_t)m; i += 256)
         next[i] = reinterpret_cast<const int16_t*>(a.blob + kTableOff)[i];
+    __syncthreads();
     const uint32_t p0 = a.blob[0];
 
     uint32_t hits = 0;
-    for (uint64_t t = tile_first + blockIdx.x; t < tile_first + ntiles; t += gridDim.x) {
-        const uint64_t tile0 = t * TB;
-        __syncthreads();
-        stage_tile<THREADS, TB>(txt, a.text + tile0);
-        stage_bytes<THREADS>(txt + TB, a.text + tile0 + TB, FH16);
-        __syncthreads();
-        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+    const uint64_t nthreads = (uint64_t)gridDim.x * 256;
+    // segments are cut on absolute offsets (multiples of seg_len, itself a multiple of 16)
+    const uint64_t seg_first = a.s_begin / seg_len;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < nsegs; g += nthreads) {
+        const uint64_t seg = (seg_first + g) * seg_len;
         const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
-        const uint64_t sb = seg + L < a.s_end ? seg + L : a.s_end;
-        if (sa < sb) {
-            const uint32_t j0 = (uint32_t)(sa - tile0);
-            const uint32_t jend = (uint32_t)(sb - tile0) + (uint32_t)m - 1;
-            int st = 0;  // pattern bytes matched so far (kmp.c: i)
-            for (uint32_t base = j0 & ~15u; base < jend; base += 16) {
-                const uint4 v = *reinterpret_cast<const uint4*>(txt + base);
-                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const uint32_t j = base + q;
-                    const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
-                    const bool live = (j >= j0) & (j < jend);
-                    if (live) {
-                        if (st == 0) {
-                            st = (c == p0) ? 1 : 0;  // next[0] = -1, then ++ (kmp.c:57-60)
-                        } else {
-                            while (st >= 0 && pat[st] != c) st = next[st];
-                            ++st;
-                        }
-                        if (st >= m) {  // kmp.c:61-64
-                            ++hits;
-                            st = next[m];
-                        }
-                    }
-                }
-            }
+        const uint64_t sb = seg + seg_len < a.s_end ? seg + seg_len : a.s_end;
+        if (sa >= sb) continue;
+        // bytes [sa, sb+m-1), addressed relative to the 16-byte-aligned segment base
+        const uint8_t* base = a.text + seg;
+        const uint32_t j0 = (uint32_t)(sa - seg);
+        const uint32_t jend = (uint32_t)(sb - seg) + (uint32_t)m - 1;
+        int st = 0;
+        uint32_t j = j0 & ~15u;
+        uint4 cur = *reinterpret_cast<const uint4*>(base + j);
+        // head chunk (may start inside it), full chunks, tail chunk
+        if (j < j0 || j + 16 > jend) {
+            kmp_chunk<true>(cur, j, j0, jend, st, hits, m, p0, pat, next);
+            j += 16;
+            if (j < jend) cur = *reinterpret_cast<const uint4*>(base + j);
         }
+        while (j + 16 <= jend) {
+            const uint4 nxt = *reinterpret_cast<const uint4*>(base + j + 16);  // in the back pad at worst
+            kmp_chunk<false>(cur, j, j0, jend, st, hits, m, p0, pat, next);
+            cur = nxt;
+            j += 16;
+        }
+        if (j < jend) kmp_chunk<true>(cur, j, j0, jend, st, hits, m, p0, pat, next);
     }
     flush_hits(hits, a.count);
 }
@@ -722,7 +796,6 @@ constexpr int kHorT = 256, kHorL = 64;
 constexpr int kBmT = 256, kBmL = 64;
 constexpr int kBndmT = 256, kBndmL = 64;
 constexpr int kSoT = 256, kSoL = 80;
-constexpr int kKmpT = 128, kKmpL = 272;
 constexpr int kEpsmT = 256;
 
 static int hor_regime(uint32_t m);
@@ -811,14 +884,30 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             return launch_tiled(bndm_scan<kBndmT, kBndmL>, a, tr, kBndmT, lds, 8, num_cus, stream);
         }
         case SMARTGPU_SO: {
-            const size_t lds = 1024 + (size_t)kSoT * kSoL + 32;
+            const size_t lds = 1040 + (size_t)kSoT * kSoL + 32;
             const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kSoT * kSoL);
-            return launch_tiled(so_scan<kSoT, kSoL>, a, tr, kSoT, lds, 6, num_cus, stream);
+            if (m > 32) return launch_tiled(so_scan<kSoT, kSoL, true>, a, tr, kSoT, lds, 6, num_cus, stream);
+            return launch_tiled(so_scan<kSoT, kSoL, false>, a, tr, kSoT, lds, 6, num_cus, stream);
         }
         case SMARTGPU_KMP: {
-            const size_t lds = r16(m) + r16(2 * (m + 1)) + (size_t)kKmpT * kKmpL + r16(m - 1);
-            const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kKmpT * kKmpL);
-            return launch_tiled(kmp_scan<kKmpT, kKmpL>, a, tr, kKmpT, lds, 3, num_cus, stream);
+            // run length per lane: re-scan overhead (m-1)/L <= 1/8 when the text is long
+            // enough, never above 1/2, and at least ~16 waves per CU worth of runs
+            const uint64_t span = a.s_end - a.s_begin;
+            uint64_t L = 8ull * (m - 1);
+            const uint64_t fill = span / ((uint64_t)num_cus * 16 * 64);
+            if (L > fill) L = fill;
+            if (L < 2ull * (m - 1)) L = 2ull * (m - 1);
+            if (L < 256) L = 256;
+            L = (L + 15) & ~15ull;
+            const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
+            if (tr.count == 0) return hipSuccess;
+            const size_t lds = r16(m) + r16(2 * (m + 1));
+            uint64_t grid = ((uint64_t)tr.count + 255) / 256;
+            const uint64_t cap = (uint64_t)num_cus * 8;
+            if (grid > cap) grid = cap;
+            hipLaunchKernelGGL(kmp_scan, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
+                               (uint64_t)tr.count);
+            return hipGetLastError();
         }
         case SMARTGPU_EPSM: {
             ScanArgs b = a;
