@@ -4,7 +4,7 @@
 Metric (BASELINE.json): GB/s of text scanned, bit-exact occurrence count,
 Horspool m=32 on 1 GiB of rand128 per GPU.
 
-    python bench.py [--gpus N --steps K --warmup W] [--algo hor --m 32 --sigma 128 --gib 1]
+    python bench.py [--gpus N --steps K --warmup W] [--algo hor --plen 32 --sigma 128 --gib 1]
 
 One "step" = one search: one pattern (cut from the text at a seeded offset, as
 setOfRandomPatterns does, src/smart.c:148-158) scanned over the whole resident
@@ -59,13 +59,16 @@ def load_traffic(kernel, workload_key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--algo", default="hor")
-    ap.add_argument("--m", type=int, default=32)
+    ap.add_argument("--plen", dest="m", type=int, default=32, help="pattern length m")
     ap.add_argument("--sigma", type=int, default=128)
     ap.add_argument("--gib", type=float, default=1.0, help="text GiB per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (needs --backend gloo); the numbers mean nothing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -78,13 +81,30 @@ def main():
     import smart_amd
     from smart_amd import Plan, Text, engine
 
+    if args.share_gpu:
+        local_rank = 0
     if smart_amd.device_count() <= local_rank:
         raise SystemExit("no GPU for local rank %d: %s" % (local_rank, engine.lib().smartgpu_last_error().decode()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
+    on_host = dist is not None and args.backend != "nccl"  # gloo rehearsal reduces host copies
+
+    def all_reduce_counts(t, op=None):
+        if dist is None:
+            return t
+        if on_host:
+            h = t.cpu()
+            dist.all_reduce(h) if op is None else dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t) if op is None else dist.all_reduce(t, op=op)
+        return t
 
     K, W, m, algo = args.steps, args.warmup, args.m, args.algo
     shard = int(args.gib * (1 << 30))
@@ -126,8 +146,7 @@ def main():
         if mark:
             engine.stream_mark(local_rank, 1)
         engine.device_sync(local_rank)          # counts are in HBM
-        if dist is not None:
-            dist.all_reduce(counts[lo:hi])     # ONE RCCL sum of the K counts over xGMI
+        all_reduce_counts(counts[lo:hi])       # ONE RCCL sum of the K counts over xGMI
         return counts[lo:hi].cpu()             # ... and on the host (SMART's run_time ends here)
 
     barrier()
@@ -141,7 +160,7 @@ def main():
 
     if dist is not None:
         tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        all_reduce_counts(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(tt[0]), float(tt[1])
 
     # ---- verification (outside the timed region) -------------------------------
@@ -155,8 +174,7 @@ def main():
         pl.launch(text, slot=0)
         oplans.append(pl)
     engine.device_sync(local_rank)
-    if dist is not None:
-        dist.all_reduce(check)
+    all_reduce_counts(check)
     want = check.cpu().numpy().astype(np.uint64)
     if not np.array_equal(got, want):
         raise SystemExit("COUNT MISMATCH %s vs %s: %s != %s" % (algo, other, got.tolist(), want.tolist()))
@@ -203,6 +221,7 @@ def main():
                           "sample": "1 pattern, text split by core with (m-1) overlap"},
         }
 
+    read_probe = engine.probe_read_gbs(text) if rank == 0 else None
     if rank == 0:
         bytes_per_launch = local_len                       # algorithmic bytes: every text byte once
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
@@ -224,7 +243,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": plans[0].kernel_name, "kernel_ms": round(kernel_ms, 4),
-                         "bytes_per_launch": bytes_per_launch},
+                         "bytes_per_launch": bytes_per_launch,
+                         "measured_stream_read_GBps": round(read_probe, 1),
+                         "frac_of_measured_stream_read": round(achieved / read_probe, 4)},
             "cpu_baseline": cpu,
             "counts_verified": "all %d counts equal the %s kernel%s" % (K, other, " and the CPU sample" if cpu else ""),
         }

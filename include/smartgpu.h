@@ -136,6 +136,11 @@ int smartgpu_stream_mark(int device, int which /* 0 = begin, 1 = end */);
 int smartgpu_stream_elapsed_ms(int device, double *ms); /* waits for mark 1 */
 void *smartgpu_stream_handle(int device);               /* hipStream_t of the library on `device` */
 
+/* Measures the device's practical streaming-read rate on this text (a plain
+ * coalesced read-and-fold kernel, `reps` passes): the "measured streaming read"
+ * the scan kernels are compared with besides the 8 TB/s spec peak. */
+int smartgpu_probe_read_ms(const smartgpu_text *t, int reps, double *ms_per_pass);
+
 /* Kernel-variant selection for experiments and A/B measurements (not needed in
  * normal use): key 0 = Horspool variant, 0 auto / 1 flat LDS tile / 2 bank-private. */
 int smartgpu_tune(int key, int value);

@@ -489,6 +489,30 @@ int smartgpu_stream_elapsed_ms(int device, double* ms)
     return SMARTGPU_OK;
 }
 
+int smartgpu_probe_read_ms(const smartgpu_text* t, int reps, double* ms_per_pass)
+{
+    if (!t || reps < 1 || !ms_per_pass) { set_error("bad probe arguments"); return SMARTGPU_ERR_ARG; }
+    DeviceCtx* d = device_ctx(t->device);
+    if (!d) return SMARTGPU_ERR_HIP;
+    unsigned long long* sink = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sink), 8), return SMARTGPU_ERR_HIP);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0), return SMARTGPU_ERR_HIP);
+    HIP_TRY(hipEventCreate(&e1), return SMARTGPU_ERR_HIP);
+    sg::launch_probe_read(t->data(), t->n, sink, d->num_cus, d->stream);  // warm-up
+    hipEventRecord(e0, d->stream);
+    for (int i = 0; i < reps; ++i) sg::launch_probe_read(t->data(), t->n, sink, d->num_cus, d->stream);
+    hipEventRecord(e1, d->stream);
+    HIP_TRY(hipEventSynchronize(e1), return SMARTGPU_ERR_HIP);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *ms_per_pass = ms / reps;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(sink);
+    return SMARTGPU_OK;
+}
+
 int smartgpu_tune(int key, int value)
 {
     if (key < 0 || key >= 8) { set_error("tune key %d out of range", key); return SMARTGPU_ERR_ARG; }

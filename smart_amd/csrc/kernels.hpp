@@ -56,4 +56,7 @@ hipError_t launch_generate(uint8_t* dst, uint64_t seed, int sigma, uint64_t off,
 hipError_t launch_tile_fill(uint8_t* dst, const uint8_t* unit, uint64_t unit_len, uint64_t phase,
                             uint64_t n, hipStream_t stream);
 
+hipError_t launch_probe_read(const uint8_t* text, uint64_t n, unsigned long long* sink, int num_cus,
+                             hipStream_t stream);
+
 }  // namespace sg

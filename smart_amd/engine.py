@@ -65,6 +65,7 @@ def lib():
         "smartgpu_stream_elapsed_ms": (i32, [i32, C.POINTER(C.c_double)]),
         "smartgpu_stream_handle": (vp, [i32]),
         "smartgpu_tune": (i32, [i32, i32]),
+        "smartgpu_probe_read_ms": (i32, [vp, i32, C.POINTER(C.c_double)]),
     }
     for a in ALGOS:
         sig["smartgpu_%s_search" % a] = (i32, [vp, i32, vp, i32])
@@ -243,6 +244,14 @@ def stream_elapsed_ms(device):
     if lib().smartgpu_stream_elapsed_ms(device, C.byref(ms)) != 0:
         raise _err("stream_elapsed_ms")
     return float(ms.value)
+
+
+def probe_read_gbs(text, reps=20):
+    """Practical streaming-read rate (GB/s) of the device on this text."""
+    ms = C.c_double(0.0)
+    if lib().smartgpu_probe_read_ms(text._h, reps, C.byref(ms)) != 0:
+        raise _err("probe_read")
+    return len(text) / (ms.value * 1e-3) / 1e9
 
 
 def tune(key, value):

@@ -38,6 +38,7 @@ def main():
         smart_amd.engine.tune(int(k), int(v))
     n = int(args.gib * (1 << 30))
     text = Text.generate(SEED, args.sigma, n)
+    print("streaming-read probe: %.1f GB/s" % smart_amd.engine.probe_read_gbs(text), flush=True)
     rows = []
     for m in [int(x) for x in args.ms.split(",")]:
         pats = []
