@@ -532,22 +532,22 @@ __global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a, uint64_t tile_fir
                         sv[q] = S[(j >= j0 && j < jend) ? c : 256u];
                     }
                 }
+                // recurrence on registers; the sign bit of D after byte q is the "no hit"
+                // flag and is shifted into H with one v_alignbit (bit 15-q of H <-> byte q)
+                uint32_t H = 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    D = (D << 1) | sv[q];                        // so.c:55
+                    H = __builtin_amdgcn_alignbit(H, D, 31);     // H = (H << 1) | (D >> 31); so.c:56
+                }
+                uint32_t hm = ~H & 0xFFFFu;
                 if (!LONG) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        D = (D << 1) | sv[q];      // so.c:55
-                        hits += (int32_t)D >= 0;  // so.c:56
-                    }
+                    hits += __popc(hm);
                 } else {
-                    uint32_t hm = 0;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        D = (D << 1) | sv[q];
-                        hm |= ((int32_t)D >= 0) ? (1u << q) : 0u;
-                    }
-                    while (hm) {  // 32-byte prefix matched at tile0+base+q-31: verify P[32..m)
-                        const uint32_t q = __builtin_ctz(hm);
-                        hm &= hm - 1;
+                    while (hm) {  // 32-byte prefix matched, ending at byte q: verify P[32..m)
+                        const uint32_t bit = 31u - __builtin_clz(hm);
+                        hm &= ~(1u << bit);
+                        const uint32_t q = 15u - bit;
                         const uint64_t h = tile0 + base + q - (w - 1);
                         hits += global_equal(a.text + h + w, a.blob + w, m - w);
                     }
@@ -560,87 +560,160 @@ __global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a, uint64_t tile_fir
 
 // ---------------------------------------------------------------------------
 // Knuth-Morris-Pratt  (reference: src/algos/kmp.c:27-68)
-//
-// The automaton is serial per lane, so the text is NOT staged through LDS: each
-// lane streams its own run of `seg_len` start positions straight from HBM/L2,
-// 16 bytes per load with the next chunk prefetched, restarts in state 0 at its
-// first start position and scans m-1 bytes into the next lane's run (SURVEY.md
-// §7 restart table).  seg_len is chosen on the host (>= 2(m-1), so the re-scan
-// is bounded, and small enough to keep every SIMD populated).  A lane's 128-B
-// line is consumed over 8 consecutive loads and stays in L2 meanwhile; the
-// kernel is bound by the per-byte dependency chain, not by memory.
-// LDS holds only the tables: pattern | i16 next[m+1].
+// Tiles indexed by START position, forward halo m-1.  A lane restarts in state 0
+// at its first start position and scans m-1 bytes into the next lane's run
+// (SURVEY.md §7 restart table), so the run length L is picked from m on the
+// host (launch_scan) to bound that re-scan.  Lanes read their runs from LDS in
+// 16-byte chunks (L/16 odd => distinct bank groups).  Used for m <= 40; longer
+// patterns need longer runs than LDS tiles allow and go to kmp_stream below.
+// LDS: u32 tab[m] | text [tile0, tile0+TB+halo)
 // State 0 (by far the most common on large alphabets) is handled in registers:
 // next[0] = -1, so the step is st = (c == P[0]) (kmp.c:57-60).
 // ---------------------------------------------------------------------------
+// One 16-byte chunk of the automaton.  tab[i] = P[i] << 16 | (uint16)next[i], so a
+// state costs one LDS read.  The branch into the table-driven step is taken per
+// WAVE (ballot): on large alphabets most steps find every lane in state 0 and
+// cost four VALU instructions.
 template <bool CHECK>
 __device__ __forceinline__ void kmp_chunk(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
-                                          int& st, uint32_t& hits, int m, uint32_t p0,
-                                          const uint8_t* __restrict__ pat,
-                                          const int16_t* __restrict__ next)
+                                          int& st, uint32_t& hits, int m, uint32_t p0, int next_m,
+                                          const uint32_t* __restrict__ tab)
 {
     const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+        bool live = true;
         if (CHECK) {
             const uint32_t j = j_base + q;
-            if (j < j0 || j >= jend) continue;
+            live = j >= j0 && j < jend;
         }
-        if (st == 0) {
-            st = (c == p0) ? 1 : 0;
-        } else {
-            while (st >= 0 && pat[st] != c) st = next[st];
-            ++st;
+        const bool slow = live && st != 0;
+        int st_new = (c == p0) ? 1 : 0;  // from state 0: next[0] = -1, then ++ (kmp.c:57-60)
+        if (__any(slow)) {
+            if (slow) {
+                int s2 = st;
+                uint32_t e = tab[s2];
+                while ((e >> 16) != c) {       // kmp.c:57-58
+                    s2 = (int16_t)(e & 0xFFFFu);
+                    if (s2 < 0) break;
+                    e = tab[s2];
+                }
+                ++s2;
+                if (s2 >= m) {                 // kmp.c:61-64
+                    ++hits;
+                    s2 = next_m;
+                }
+                st_new = s2;
+            }
         }
-        if (st >= m) {  // kmp.c:61-64
-            ++hits;
-            st = next[m];
-        }
+        st = live ? st_new : st;
     }
 }
 
-__global__ __launch_bounds__(256) void kmp_scan(ScanArgs a, uint32_t seg_len, uint64_t nsegs)
+template <int THREADS, int L>
+__global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a, uint64_t tile_first,
+                                                    uint32_t ntiles)
+{
+    constexpr int TB = THREADS * L;
+    static_assert((L / 16) % 2 == 1, "L/16 must be odd (LDS bank spread)");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int m = (int)a.m;
+    const uint32_t FH16 = round16(a.halo);  // forward halo, a.halo = m-1
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* txt = smem + round16(4 * m);
+    const int16_t* gnext = reinterpret_cast<const int16_t*>(a.blob + kTableOff);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)m; i += THREADS)
+        tab[i] = ((uint32_t)a.blob[i] << 16) | (uint16_t)gnext[i];
+    const uint32_t p0 = a.blob[0];
+    const int next_m = gnext[m];
+
+    uint32_t hits = 0;
+    for (uint64_t t = tile_first + blockIdx.x; t < tile_first + ntiles; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();
+        stage_tile<THREADS, TB>(txt, a.text + tile0);
+        stage_bytes<THREADS>(txt + TB, a.text + tile0 + TB, FH16);
+        __syncthreads();
+        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
+        const uint64_t sb = seg + L < a.s_end ? seg + L : a.s_end;
+        if (sa >= sb) continue;
+        // bytes [sa, sb+m-1) of the tile, as LDS offsets
+        const uint32_t j0 = (uint32_t)(sa - tile0);
+        const uint32_t jend = (uint32_t)(sb - tile0) + (uint32_t)m - 1;
+        uint32_t j = j0 & ~15u;
+        if (m == 1) {  // no automaton: count the bytes equal to P[0]
+            for (; j < jend; j += 16) {
+                const uint4 v = *reinterpret_cast<const uint4*>(txt + j);
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+                    hits += (c == p0) && (j + q >= j0) && (j + q < jend);
+                }
+            }
+            continue;
+        }
+        int st = 0;
+        // head chunk (may start inside it), full chunks, tail chunk
+        if (j < j0 || j + 16 > jend) {
+            kmp_chunk<true>(*reinterpret_cast<const uint4*>(txt + j), j, j0, jend, st, hits, m, p0, next_m, tab);
+            j += 16;
+        }
+        for (; j + 16 <= jend; j += 16)
+            kmp_chunk<false>(*reinterpret_cast<const uint4*>(txt + j), j, j0, jend, st, hits, m, p0, next_m, tab);
+        if (j < jend)
+            kmp_chunk<true>(*reinterpret_cast<const uint4*>(txt + j), j, j0, jend, st, hits, m, p0, next_m, tab);
+    }
+    flush_hits(hits, a.count);
+}
+
+// Streaming variant for m > 40: no LDS text tile; each lane streams its own run
+// of `seg_len` start positions straight from memory, 16 bytes per load with the
+// next chunk prefetched.  64 lanes x 16 B from 64 different lines per wave-load
+// is a poor access pattern (it tops out near 1.1 TB/s even with no automaton
+// work), but a lane's run can be as long as the re-scan of m-1 bytes requires,
+// which LDS tiles cannot offer at useful occupancy.
+__global__ __launch_bounds__(256) void kmp_stream(ScanArgs a, uint32_t seg_len, uint64_t nsegs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int m = (int)a.m;
-    uint8_t* pat = smem;
-    int16_t* next = reinterpret_cast<int16_t*>(smem + round16(m));
-    for (uint32_t i = threadIdx.x; i < (uint32_t)m; i += 256) pat[i] = a.blob[i];
-    for (uint32_t i = threadIdx.x; i <= (uint32_t)m; i += 256)
-        next[i] = reinterpret_cast<const int16_t*>(a.blob + kTableOff)[i];
+    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
+    const int16_t* gnext = reinterpret_cast<const int16_t*>(a.blob + kTableOff);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)m; i += 256)
+        tab[i] = ((uint32_t)a.blob[i] << 16) | (uint16_t)gnext[i];
     __syncthreads();
     const uint32_t p0 = a.blob[0];
+    const int next_m = gnext[m];
 
     uint32_t hits = 0;
     const uint64_t nthreads = (uint64_t)gridDim.x * 256;
-    // segments are cut on absolute offsets (multiples of seg_len, itself a multiple of 16)
+    // runs are cut on absolute offsets (multiples of seg_len, itself a multiple of 16)
     const uint64_t seg_first = a.s_begin / seg_len;
     for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < nsegs; g += nthreads) {
         const uint64_t seg = (seg_first + g) * seg_len;
         const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
         const uint64_t sb = seg + seg_len < a.s_end ? seg + seg_len : a.s_end;
         if (sa >= sb) continue;
-        // bytes [sa, sb+m-1), addressed relative to the 16-byte-aligned segment base
-        const uint8_t* base = a.text + seg;
+        const uint8_t* base = a.text + seg;  // 16-byte aligned
         const uint32_t j0 = (uint32_t)(sa - seg);
         const uint32_t jend = (uint32_t)(sb - seg) + (uint32_t)m - 1;
-        int st = 0;
         uint32_t j = j0 & ~15u;
         uint4 cur = *reinterpret_cast<const uint4*>(base + j);
-        // head chunk (may start inside it), full chunks, tail chunk
+        int st = 0;
         if (j < j0 || j + 16 > jend) {
-            kmp_chunk<true>(cur, j, j0, jend, st, hits, m, p0, pat, next);
+            kmp_chunk<true>(cur, j, j0, jend, st, hits, m, p0, next_m, tab);
             j += 16;
             if (j < jend) cur = *reinterpret_cast<const uint4*>(base + j);
         }
         while (j + 16 <= jend) {
             const uint4 nxt = *reinterpret_cast<const uint4*>(base + j + 16);  // in the back pad at worst
-            kmp_chunk<false>(cur, j, j0, jend, st, hits, m, p0, pat, next);
+            kmp_chunk<false>(cur, j, j0, jend, st, hits, m, p0, next_m, tab);
             cur = nxt;
             j += 16;
         }
-        if (j < jend) kmp_chunk<true>(cur, j, j0, jend, st, hits, m, p0, pat, next);
+        if (j < jend) kmp_chunk<true>(cur, j, j0, jend, st, hits, m, p0, next_m, tab);
     }
     flush_hits(hits, a.count);
 }
@@ -877,7 +950,7 @@ const char* scan_kernel_name(int algo, uint32_t m)
             return r == 3 ? "packed_scan" : r == 2 ? "hor_scan_bp" : "hor_scan";
         }
         case SMARTGPU_BM: return "bm_scan";
-        case SMARTGPU_KMP: return "kmp_scan";
+        case SMARTGPU_KMP: return m <= 40 ? "kmp_scan" : "kmp_stream";
         case SMARTGPU_SO: return "so_scan";
         case SMARTGPU_BNDM: return "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
@@ -959,8 +1032,23 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             return launch_tiled(so_scan<kSoT, kSoL, false>, a, tr, kSoT, lds, 6, num_cus, stream);
         }
         case SMARTGPU_KMP: {
-            // run length per lane: re-scan overhead (m-1)/L <= 1/8 when the text is long
-            // enough, never above 1/2, and at least ~16 waves per CU worth of runs
+            // m <= 40: LDS tiles, run length per lane 80 or 144 bytes (re-scan of m-1 bytes <~28 %)
+            const size_t fixed = r16(4 * m) + r16(m - 1);
+#define SG_KMP(T_, L_, WGS_)                                                                   \
+    do {                                                                                       \
+        const size_t lds = fixed + (size_t)(T_) * (L_);                                        \
+        if (lds > 64 * 1024)                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kmp_scan<T_, L_>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)(T_) * (L_));            \
+        return launch_tiled(kmp_scan<T_, L_>, a, tr, T_, lds, WGS_, num_cus, stream);          \
+    } while (0)
+            if (m <= 16) SG_KMP(256, 80, 6);
+            if (m <= 40) SG_KMP(256, 144, 4);
+#undef SG_KMP
+            // m > 40: per-lane streaming runs (see kmp_stream); run length: re-scan overhead
+            // (m-1)/L <= 1/8 when the text is long enough, never above 1/2, and short enough
+            // to give every CU ~16 waves of runs
             const uint64_t span = a.s_end - a.s_begin;
             uint64_t L = 8ull * (m - 1);
             const uint64_t fill = span / ((uint64_t)num_cus * 16 * 64);
@@ -970,11 +1058,10 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             L = (L + 15) & ~15ull;
             const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
             if (tr.count == 0) return hipSuccess;
-            const size_t lds = r16(m) + r16(2 * (m + 1));
             uint64_t grid = ((uint64_t)tr.count + 255) / 256;
             const uint64_t cap = (uint64_t)num_cus * 8;
             if (grid > cap) grid = cap;
-            hipLaunchKernelGGL(kmp_scan, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
+            hipLaunchKernelGGL(kmp_stream, dim3((uint32_t)grid), dim3(256), r16(4 * m), stream, a, (uint32_t)L,
                                (uint64_t)tr.count);
             return hipGetLastError();
         }
