@@ -69,12 +69,56 @@ __device__ __forceinline__ void flush_hits(uint32_t lane_hits, unsigned long lon
     if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(out, v);
 }
 
+// Equality of `len` bytes in memory, 16 bytes per step (gfx950 global loads may be
+// unaligned: an align-1 16-byte copy compiles to one global_load_dwordx4).
 __device__ __forceinline__ bool global_equal(const uint8_t* __restrict__ a,
                                              const uint8_t* __restrict__ b, uint32_t len)
 {
     uint32_t i = 0;
-    while (i < len && a[i] == b[i]) ++i;
-    return i == len;
+    for (; i + 16 <= len; i += 16) {
+        uint4 x, y;
+        __builtin_memcpy(&x, a + i, 16);
+        __builtin_memcpy(&y, b + i, 16);
+        if ((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) return false;
+    }
+    for (; i < len; ++i)
+        if (a[i] != b[i]) return false;
+    return true;
+}
+
+// Wave-cooperative verification.  A candidate that survived the in-LDS filter of
+// a long pattern still needs `len` more bytes compared in memory; done by its own
+// lane that is a serial chain of dependent loads (0.5 ms for ONE m=4096 match —
+// measured), so each lane parks its first candidate of a tile and, at a
+// wave-uniform point, the 64 lanes compare 1 KiB per step together.
+// Returns 1 in the lane whose candidate verified, 0 elsewhere.
+__device__ __forceinline__ uint32_t wave_verify(bool has, const uint8_t* tptr,
+                                                const uint8_t* __restrict__ pptr, uint32_t len)
+{
+    unsigned long long todo = __ballot(has);
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t mine = 0;
+    while (todo) {
+        const int src = __builtin_ctzll(todo);  // wave-uniform
+        todo &= todo - 1;
+        const unsigned long long tp = (unsigned long long)tptr;
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)tp, src);
+        const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(tp >> 32), src);
+        const uint8_t* t = reinterpret_cast<const uint8_t*>(((unsigned long long)hi << 32) | lo);
+        bool diff = false;
+        for (uint32_t off = lane * 16u; off < len; off += 1024u) {
+            if (off + 16u <= len) {
+                uint4 x, y;
+                __builtin_memcpy(&x, t + off, 16);
+                __builtin_memcpy(&y, pptr + off, 16);
+                diff |= ((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) != 0;
+            } else {
+                for (uint32_t i = off; i < len; ++i) diff |= t[i] != pptr[i];
+            }
+        }
+        if (!__any(diff) && lane == (uint32_t)src) mine = 1;
+    }
+    return mine;
 }
 
 // ---------------------------------------------------------------------------
@@ -130,6 +174,8 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
         const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
         const uint64_t lo = seg > e_begin ? seg : e_begin;
         const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+        bool parked = false;  // first candidate of this tile awaiting wave_verify
+        const uint8_t* parked_at = a.text;
         if (lo < hi) {
             uint32_t e = (uint32_t)(lo - tile0) + H16;
             const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
@@ -139,15 +185,22 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
                     uint32_t k = 1;  // bytes matched so far, right to left
                     while (k <= H && ptail[H - k] == txt[e - k]) ++k;
                     bool ok = k > H;
-                    if (ok && m - 1 > H) {
-                        const uint64_t s = tile0 + (e - H16) - (m - 1);
-                        ok = global_equal(a.text + s, a.blob, m - 1 - H);
+                    if (ok && m - 1 > H) {  // the rest of the window is not in LDS
+                        const uint8_t* rest = a.text + tile0 + (e - H16) - (m - 1);
+                        if (!parked) {
+                            parked = true;
+                            parked_at = rest;
+                            ok = false;  // counted by wave_verify below
+                        } else {
+                            ok = global_equal(rest, a.blob, m - 1 - H);
+                        }
                     }
                     hits += ok;
                 }
                 e += ent & 0x7FFFu;
             }
         }
+        if (m - 1 > H) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
     flush_hits(hits, a.count);
 }
@@ -290,11 +343,11 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
     const uint32_t m = a.m, H = a.halo, H16 = round16(H);
     uint16_t* bc = reinterpret_cast<uint16_t*>(smem);
     uint16_t* gs = bc + 256;
-    uint8_t* ptail = smem + 512 + round16(2 * m);
+    uint8_t* ptail = smem + 512 + round16(2 * (m + 1));
     uint8_t* txt = ptail + round16(H + 1);
 
     const uint16_t* gtab = reinterpret_cast<const uint16_t*>(a.blob + kTableOff);
-    for (uint32_t i = threadIdx.x; i < 256 + m; i += THREADS) bc[i] = gtab[i];
+    for (uint32_t i = threadIdx.x; i < 256 + m + 1; i += THREADS) bc[i] = gtab[i];  // bc, gs[0..m-1], safe shift
     for (uint32_t i = threadIdx.x; i <= H; i += THREADS) ptail[i] = a.blob[m - 1 - H + i];
 
     const uint64_t e_begin = a.s_begin + m - 1, e_end = a.s_end + m - 1;
@@ -329,6 +382,8 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
         const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
         const uint64_t lo = seg > e_begin ? seg : e_begin;
         const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+        bool parked = false;  // first candidate of this tile awaiting wave_verify
+        const uint8_t* parked_at = a.text;
         if (lo < hi) {
             uint32_t e = (uint32_t)(lo - tile0) + H16;
             const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
@@ -341,16 +396,28 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
                     if (c != ptail[H - k]) { mismatch = true; break; }
                     ++k;
                 }
-                if (!mismatch && k < m) {  // the halo is exhausted: go on in HBM
+                bool deferred = false;
+                if (!mismatch && k < m) {  // the halo is exhausted: the rest is in HBM
                     const uint8_t* tp = a.text + tile0 + (e - H16);
-                    while (k < m) {
-                        c = tp[-(int64_t)k];
-                        if (c != a.blob[m - 1 - k]) { mismatch = true; break; }
-                        ++k;
+                    if (!parked) {
+                        // park the first candidate of the tile for wave_verify; move on by a
+                        // shift that is safe whatever the outcome (min of gs over the
+                        // positions still unchecked, computed on the host)
+                        parked = true;
+                        parked_at = tp - (m - 1);
+                        deferred = true;
+                    } else {
+                        while (k < m) {
+                            c = tp[-(int64_t)k];
+                            if (c != a.blob[m - 1 - k]) { mismatch = true; break; }
+                            ++k;
+                        }
                     }
                 }
                 uint32_t shift;
-                if (!mismatch) {
+                if (deferred) {
+                    shift = gs[m];  // safe shift (see api.cpp build_blob)
+                } else if (!mismatch) {
                     ++hits;
                     shift = gs[0];  // bm.c:86
                 } else {
@@ -361,6 +428,7 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
                 e += shift;
             }
         }
+        if (m - 1 > H) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
     flush_hits(hits, a.count);
 }
@@ -415,6 +483,8 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
         const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
         const uint64_t lo = seg > e_begin ? seg : e_begin;
         const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+        bool parked = false;  // first candidate of this tile awaiting wave_verify
+        const uint8_t* parked_at = a.text;
         if (lo < hi) {
             uint32_t e = (uint32_t)(lo - tile0) + H16;
             const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
@@ -433,8 +503,13 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
                         } else {
                             // prefix of 32 matched: verify P[32..m) (bndm.c:99-102),
                             // the window is inside the text because s < s_end
-                            const uint64_t s = tile0 + (e - H16) - (w - 1);
-                            hits += global_equal(a.text + s + w, a.blob + w, m - w);
+                            const uint8_t* rest = a.text + tile0 + (e - H16) + 1;  // = text + s + w
+                            if (!parked) {
+                                parked = true;
+                                parked_at = rest;
+                            } else {
+                                hits += global_equal(rest, a.blob + w, m - w);
+                            }
                         }
                     }
                     D <<= 1;
@@ -442,6 +517,7 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
                 e += last;
             }
         }
+        if (m > w) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
     }
     flush_hits(hits, a.count);
 }
@@ -511,6 +587,8 @@ __global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a, uint64_t tile_fir
         const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
         const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
         const uint64_t sb = seg + L < a.s_end ? seg + L : a.s_end;
+        bool parked = false;  // first candidate of this tile awaiting wave_verify
+        const uint8_t* parked_at = a.text;
         if (sa < sb) {
             const uint32_t j0 = (uint32_t)(sa - tile0);
             const uint32_t jend = (uint32_t)(sb - tile0) + w - 1;
@@ -548,12 +626,18 @@ __global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a, uint64_t tile_fir
                         const uint32_t bit = 31u - __builtin_clz(hm);
                         hm &= ~(1u << bit);
                         const uint32_t q = 15u - bit;
-                        const uint64_t h = tile0 + base + q - (w - 1);
-                        hits += global_equal(a.text + h + w, a.blob + w, m - w);
+                        const uint8_t* rest = a.text + tile0 + base + q + 1;  // = text + h + w
+                        if (!parked) {
+                            parked = true;
+                            parked_at = rest;
+                        } else {
+                            hits += global_equal(rest, a.blob + w, m - w);
+                        }
                     }
                 }
             }
         }
+        if (LONG) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
     }
     flush_hits(hits, a.count);
 }
@@ -774,12 +858,19 @@ static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const Eps
             cand &= eq;
         }
         if (fp.m > 16) {
+            // the lowest candidate of every lane goes to wave_verify, further ones (rare)
+            // are checked by the lane itself
             uint32_t c = cand;
+            const bool has = c != 0;
+            const uint32_t k0 = has ? __builtin_ctz(c) : 0u;
+            c &= c - 1;
+            cand &= ~(1u << k0);
             while (c) {
                 const uint32_t k = __builtin_ctz(c);
                 c &= c - 1;
                 if (!global_equal(a.text + p0 + k + 16, a.blob + 16, fp.m - 16)) cand &= ~(1u << k);
             }
+            return __popc(cand) + wave_verify(has, a.text + p0 + k0 + 16, a.blob + 16, fp.m - 16);
         }
     }
     return __popc(cand);
@@ -1015,7 +1106,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
         }
         case SMARTGPU_BM: {
             const uint32_t H = a.halo;
-            const size_t lds = 512 + r16(2 * m) + r16(H + 1) + r16(H) + (size_t)kBmT * kBmL;
+            const size_t lds = 512 + r16(2 * (m + 1)) + r16(H + 1) + r16(H) + (size_t)kBmT * kBmL;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmT * kBmL);
             return launch_tiled(bm_scan<kBmT, kBmL>, a, tr, kBmT, lds, 6, num_cus, stream);
         }

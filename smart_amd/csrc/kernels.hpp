@@ -32,7 +32,7 @@ struct ScanArgs {
 
 // Byte offsets of the tables inside the blob, after the pattern slot.
 //  HOR : u16 tab[256]   shift | 0x8000 if c == P[m-1]; u8 tab8[256]; fingerprint (as EPSM)
-//  BM  : u16 bc[256], u16 gs[m]
+//  BM  : u16 bc[256], u16 gs[m], u16 safe_shift
 //  KMP : i16 next[m+1]
 //  SO  : u32 S[256]
 //  BNDM: u32 B[256]
