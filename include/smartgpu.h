@@ -142,7 +142,9 @@ void *smartgpu_stream_handle(int device);               /* hipStream_t of the li
 int smartgpu_probe_read_ms(const smartgpu_text *t, int reps, double *ms_per_pass);
 
 /* Kernel-variant selection for experiments and A/B measurements (not needed in
- * normal use): key 0 = Horspool variant, 0 auto / 1 flat LDS tile / 2 bank-private. */
+ * normal use): key 0 = regime of the skip algorithms, 0 auto / 1 always the LDS-tile
+ * skip loop / 2 Horspool bank-private LDS layout / 3 packed matcher; key 2 = rows in
+ * flight of the packed matcher (1, 2, 4). */
 int smartgpu_tune(int key, int value);
 
 /* Host-side preprocessing exposed for tests (same tables the kernels stage in

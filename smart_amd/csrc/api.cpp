@@ -192,6 +192,8 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
                 for (uint32_t i = 0; i + 1 < m - *halo; ++i) safe = std::min(safe, gs[i]);
             tab[256 + m] = static_cast<uint16_t>(safe);
             append(tab.data(), tab.size() * 2);
+            if (blob.size() % 4) blob.resize((blob.size() + 3) & ~size_t(3), 0);
+            append_fingerprint();  // m <= 8 regime
             break;
         }
         case SMARTGPU_KMP: {
@@ -210,6 +212,7 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         case SMARTGPU_BNDM: {
             const std::vector<uint32_t> B = sg::bndm_masks(P, m);
             append(B.data(), 1024);
+            append_fingerprint();  // m <= 8 regime
             break;
         }
         case SMARTGPU_EPSM:

@@ -127,7 +127,7 @@ __device__ __forceinline__ uint32_t wave_verify(bool has, const uint8_t* tptr,
 // tab[c] = hbc[c] | 0x8000 when c == P[m-1]: the byte that selects the shift
 // also answers the first comparison, so a window costs two LDS reads.
 // ---------------------------------------------------------------------------
-template <int THREADS, int L>
+template <int THREADS, int L, bool LONG>  // LONG: m-1 > back halo, windows are completed in HBM
 __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_first,
                                                     uint32_t ntiles)
 {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
                     uint32_t k = 1;  // bytes matched so far, right to left
                     while (k <= H && ptail[H - k] == txt[e - k]) ++k;
                     bool ok = k > H;
-                    if (ok && m - 1 > H) {  // the rest of the window is not in LDS
+                    if (LONG && ok) {  // the rest of the window is not in LDS
                         const uint8_t* rest = a.text + tile0 + (e - H16) - (m - 1);
                         if (!parked) {
                             parked = true;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
                 e += ent & 0x7FFFu;
             }
         }
-        if (m - 1 > H) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
+        if (LONG) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
     flush_hits(hits, a.count);
 }
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
 // Boyer-Moore  (reference: src/algos/bm.c:27-93)
 // LDS: u16 bc[256] | u16 gs[m] | pattern tail | text [tile0-H16, tile0+TB)
 // ---------------------------------------------------------------------------
-template <int THREADS, int L>
+template <int THREADS, int L, bool LONG>  // LONG: m-1 > back halo
 __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_first,
                                                    uint32_t ntiles)
 {
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
                     ++k;
                 }
                 bool deferred = false;
-                if (!mismatch && k < m) {  // the halo is exhausted: the rest is in HBM
+                if (LONG && !mismatch && k < m) {  // the halo is exhausted: the rest is in HBM
                     const uint8_t* tp = a.text + tile0 + (e - H16);
                     if (!parked) {
                         // park the first candidate of the tile for wave_verify; move on by a
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
                 e += shift;
             }
         }
-        if (m - 1 > H) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
+        if (LONG) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
     flush_hits(hits, a.count);
 }
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
 // w = min(m,32); tiles are indexed by the END of the w-byte (prefix) window.
 // LDS: u32 B[256] | text [tile0-32, tile0+TB)
 // ---------------------------------------------------------------------------
-template <int THREADS, int L>
+template <int THREADS, int L, bool LONG>  // LONG: m > 32, prefix hits are verified
 __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_first,
                                                      uint32_t ntiles)
 {
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
                     if (D != 0) {
                         if (i >= 0) {
                             last = (uint32_t)i + 1;
-                        } else if (w == m) {
+                        } else if (!LONG) {
                             ++hits;
                         } else {
                             // prefix of 32 matched: verify P[32..m) (bndm.c:99-102),
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
                 e += last;
             }
         }
-        if (m > w) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
+        if (LONG) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
     }
     flush_hits(hits, a.count);
 }
@@ -823,8 +823,10 @@ struct EpsmFp { uint32_t f0, f1, f2, f3, k0, k1, k2, k3, nd, m; };
 #define SG_W(x) (((x) & 3) == 0 ? d[(x) >> 2] \
                                 : __builtin_amdgcn_alignbyte(d[((x) >> 2) + 1], d[(x) >> 2], (x) & 3))
 
+template <bool VERIFY>  // VERIFY: m > 16, bytes 16.. are compared in memory
 static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const EpsmFp& fp,
-                                                    const uint4& A, const uint4& Bv, uint64_t p0)
+                                                    const uint4& A, const uint4& Bv, uint64_t p0,
+                                                    uint32_t& pending)
 {
     const uint32_t d[8] = {A.x, A.y, A.z, A.w, Bv.x, Bv.y, Bv.z, Bv.w};
     // offsets k with p0+k inside [s_begin, s_end)
@@ -836,50 +838,64 @@ static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const Eps
         const uint32_t hi = hi64 > 16 ? 16u : (uint32_t)hi64;
         cand = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
     }
+    // VERIFY (m > 16) implies four full fingerprint dwords: no byte masks needed
+#define SG_EQ(x, kk, ff) (VERIFY ? (SG_W(x) == (ff)) : ((SG_W(x) & (kk)) == (ff)))
+    const uint32_t nd = VERIFY ? 4u : fp.nd;
     {
         uint32_t eq = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) eq |= ((SG_W(k) & fp.k0) == fp.f0) ? (1u << k) : 0u;
+        for (int k = 0; k < 16; ++k) eq |= SG_EQ(k, fp.k0, fp.f0) ? (1u << k) : 0u;
         cand &= eq;
     }
-    if (fp.nd > 1 && __any(cand != 0)) {
+    if (nd > 1 && __any(cand != 0)) {
         uint32_t eq = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) eq |= ((SG_W(k + 4) & fp.k1) == fp.f1) ? (1u << k) : 0u;
+        for (int k = 0; k < 16; ++k) eq |= SG_EQ(k + 4, fp.k1, fp.f1) ? (1u << k) : 0u;
         cand &= eq;
-        if (fp.nd > 2 && __any(cand != 0)) {
+        if (nd > 2 && __any(cand != 0)) {
             eq = 0;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                bool e2 = (SG_W(k + 8) & fp.k2) == fp.f2;
-                if (fp.nd > 3) e2 = e2 && ((SG_W(k + 12) & fp.k3) == fp.f3);
+                bool e2 = SG_EQ(k + 8, fp.k2, fp.f2);
+                if (nd > 3) e2 = e2 && SG_EQ(k + 12, fp.k3, fp.f3);
                 eq |= e2 ? (1u << k) : 0u;
             }
             cand &= eq;
         }
-        if (fp.m > 16) {
-            // the lowest candidate of every lane goes to wave_verify, further ones (rare)
-            // are checked by the lane itself
-            uint32_t c = cand;
-            const bool has = c != 0;
-            const uint32_t k0 = has ? __builtin_ctz(c) : 0u;
-            c &= c - 1;
-            cand &= ~(1u << k0);
-            while (c) {
-                const uint32_t k = __builtin_ctz(c);
-                c &= c - 1;
-                if (!global_equal(a.text + p0 + k + 16, a.blob + 16, fp.m - 16)) cand &= ~(1u << k);
-            }
-            return __popc(cand) + wave_verify(has, a.text + p0 + k0 + 16, a.blob + 16, fp.m - 16);
-        }
+    }
+#undef SG_EQ
+    if (VERIFY) {  // the caller verifies bytes 16.. of the survivors (epsm_verify)
+        pending = cand;
+        return 0;
     }
     return __popc(cand);
 }
 #undef SG_W
 
-// ALGO only tags the instantiation (rocprofv3 shows packed_scan<256, 4, 5> for
-// EPSM and packed_scan<256, 4, 0> for Horspool's m <= 4 regime, see launch_scan).
-template <int THREADS, int ROWS, int ALGO>
+// m > 16: candidates that matched the 16-byte fingerprint.  The lowest candidate of
+// every lane goes to wave_verify, further ones (rare) are checked by the lane itself.
+static __device__ __attribute__((noinline)) uint32_t epsm_verify(const uint8_t* text, const uint8_t* blob,
+                                                                 uint32_t m, uint32_t cand, uint64_t p0)
+{
+    // out of line on purpose: inlined, its control flow pushes the streaming loop of
+    // packed_scan over the SGPR budget (spills into the hot path, -12 % measured)
+    const uint32_t len = m - 16;
+    uint32_t c = cand;
+    const bool has = c != 0;
+    const uint32_t k0 = has ? __builtin_ctz(c) : 0u;
+    c &= c - 1;
+    cand &= ~(1u << k0);
+    while (c) {
+        const uint32_t k = __builtin_ctz(c);
+        c &= c - 1;
+        if (!global_equal(text + p0 + k + 16, blob + 16, len)) cand &= ~(1u << k);
+    }
+    return __popc(cand) + wave_verify(has, text + p0 + k0 + 16, blob + 16, len);
+}
+
+// ALGO only tags the instantiation (rocprofv3 shows packed_scan<256, 4, 5, ..> for
+// EPSM and packed_scan<256, 4, 0, ..> for Horspool's short-pattern regime).
+template <int THREADS, int ROWS, int ALGO, bool VERIFY>
 __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_first,
                                                        uint64_t nrows)
 {
@@ -902,10 +918,28 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_
             A[j] = *reinterpret_cast<const uint4*>(src);
             B[j] = *reinterpret_cast<const uint4*>(src + 16);
         }
+        uint32_t pend[ROWS];
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
+            pend[j] = 0;
             if (g + j < nrows)
-                hits += epsm_row(a, fp, A[j], B[j], ((row_first + g + j) * THREADS + threadIdx.x) * 16);
+                hits += epsm_row<VERIFY>(a, fp, A[j], B[j], ((row_first + g + j) * THREADS + threadIdx.x) * 16, pend[j]);
+        }
+        if (VERIFY) {
+            uint32_t any_pend = 0;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) any_pend |= pend[j];
+            if (__any(any_pend != 0)) {  // rare: one copy of the verification code, rows by select
+#pragma unroll 1
+                for (int j = 0; j < ROWS; ++j) {
+                    uint32_t c = pend[0];
+#pragma unroll
+                    for (int q = 1; q < ROWS; ++q)
+                        if (j == q) c = pend[q];
+                    if (__any(c != 0))
+                        hits += epsm_verify(a.text, a.blob, a.m, c, ((row_first + g + j) * THREADS + threadIdx.x) * 16);
+                }
+            }
         }
     }
     flush_hits(hits, a.count);
@@ -1023,6 +1057,7 @@ hipError_t launch_tiled(K kernel, const ScanArgs& a, TileRange tr, int threads, 
 }  // namespace
 
 int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+constexpr uint32_t kPackedMaxM = 16;  // skip algorithms use the packed matcher up to this m
 
 // tile shapes (threads, bytes per lane)
 constexpr int kHorT = 256, kHorL = 64;
@@ -1040,10 +1075,10 @@ const char* scan_kernel_name(int algo, uint32_t m)
             const int r = hor_regime(m);
             return r == 3 ? "packed_scan" : r == 2 ? "hor_scan_bp" : "hor_scan";
         }
-        case SMARTGPU_BM: return "bm_scan";
+        case SMARTGPU_BM: return (m <= kPackedMaxM && g_tune[0] != 1) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return m <= 40 ? "kmp_scan" : "kmp_stream";
         case SMARTGPU_SO: return "so_scan";
-        case SMARTGPU_BNDM: return "bndm_scan";
+        case SMARTGPU_BNDM: return (m <= kPackedMaxM && g_tune[0] != 1) ? "packed_scan" : "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
     }
     return "?";
@@ -1060,26 +1095,31 @@ static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stre
     uint64_t grid = ((uint64_t)tr.count + rows - 1) / rows;
     const uint64_t cap = (uint64_t)num_cus * 8;
     if (grid > cap) grid = cap;
-    if (rows == 1)
-        hipLaunchKernelGGL((packed_scan<kEpsmT, 1, ALGO>), dim3((uint32_t)grid), dim3(kEpsmT), 0, stream, a, tr.first, (uint64_t)tr.count);
-    else if (rows == 2)
-        hipLaunchKernelGGL((packed_scan<kEpsmT, 2, ALGO>), dim3((uint32_t)grid), dim3(kEpsmT), 0, stream, a, tr.first, (uint64_t)tr.count);
-    else
-        hipLaunchKernelGGL((packed_scan<kEpsmT, 4, ALGO>), dim3((uint32_t)grid), dim3(kEpsmT), 0, stream, a, tr.first, (uint64_t)tr.count);
+#define SG_PACKED(R_, V_)                                                                          \
+    hipLaunchKernelGGL((packed_scan<kEpsmT, R_, ALGO, V_>), dim3((uint32_t)grid), dim3(kEpsmT), 0,   \
+                       stream, a, tr.first, (uint64_t)tr.count)
+    const bool verify = a.m > 16;
+    if (rows == 1) { if (verify) SG_PACKED(1, true); else SG_PACKED(1, false); }
+    else if (rows == 2) { if (verify) SG_PACKED(2, true); else SG_PACKED(2, false); }
+    else { if (verify) SG_PACKED(4, true); else SG_PACKED(4, false); }
+#undef SG_PACKED
     return hipGetLastError();
 }
 
-// Horspool regimes (rand128, 1 GiB, measured): m <= 4 packed compare at every
-// alignment (the window is one dword: the skip loop degenerates, SURVEY.md §7
-// "hybrid"), 5..7 bank-private LDS layout, >= 8 flat LDS tile.
+// Regimes of the skip algorithms (HOR, BM, BNDM).  For m <= 16 the window is at most
+// four dwords and a skip loop degenerates (a lane advances ~m bytes per two dependent
+// LDS reads); the packed matcher tests every alignment at HBM speed instead — the
+// "hybrid" SURVEY.md §7 describes; counts are identical.  Measured on 1 GiB rand128
+// (profiles/r01): HOR m=4: flat tile 45 %, bank-private 55 %, packed 74 % of 8 TB/s;
+// BM/BNDM m=9..16: skip loop 44-58 %, packed 72 %.
+
 static int hor_regime(uint32_t m)
 {
     const int v = g_tune[0];  // 0 auto, 1 flat, 2 bank-private, 3 packed
     if (v == 3) return m <= 16 ? 3 : 1;
     if (v == 2) return m <= 255 ? 2 : 1;
     if (v == 1) return 1;
-    if (m <= 4) return 3;
-    return m < 8 ? 2 : 1;
+    return m <= kPackedMaxM ? 3 : 1;  // bank-private kernel: only on request
 }
 
 hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream)
@@ -1102,19 +1142,32 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             }
             const size_t lds = 512 + r16(H + 1) + r16(H) + (size_t)kHorT * kHorL;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
-            return launch_tiled(hor_scan<kHorT, kHorL>, a, tr, kHorT, lds, 8, num_cus, stream);
+            if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true>, a, tr, kHorT, lds, 8, num_cus, stream);
+            return launch_tiled(hor_scan<kHorT, kHorL, false>, a, tr, kHorT, lds, 8, num_cus, stream);
         }
         case SMARTGPU_BM: {
+            if (m <= kPackedMaxM && g_tune[0] != 1) {
+                ScanArgs b = a;
+                b.fp_off = kTableOff + ((512 + 2 * (m + 1) + 3) & ~3u);  // after bc, gs, safe shift
+                return launch_packed<SMARTGPU_BM>(b, num_cus, stream);
+            }
             const uint32_t H = a.halo;
             const size_t lds = 512 + r16(2 * (m + 1)) + r16(H + 1) + r16(H) + (size_t)kBmT * kBmL;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmT * kBmL);
-            return launch_tiled(bm_scan<kBmT, kBmL>, a, tr, kBmT, lds, 6, num_cus, stream);
+            if (m - 1 > H) return launch_tiled(bm_scan<kBmT, kBmL, true>, a, tr, kBmT, lds, 6, num_cus, stream);
+            return launch_tiled(bm_scan<kBmT, kBmL, false>, a, tr, kBmT, lds, 6, num_cus, stream);
         }
         case SMARTGPU_BNDM: {
+            if (m <= kPackedMaxM && g_tune[0] != 1) {
+                ScanArgs b = a;
+                b.fp_off = kTableOff + 1024;  // after B[256]
+                return launch_packed<SMARTGPU_BNDM>(b, num_cus, stream);
+            }
             const uint32_t w = m < 32 ? m : 32;
             const size_t lds = 1024 + 32 + (size_t)kBndmT * kBndmL;
             const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
-            return launch_tiled(bndm_scan<kBndmT, kBndmL>, a, tr, kBndmT, lds, 8, num_cus, stream);
+            if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true>, a, tr, kBndmT, lds, 8, num_cus, stream);
+            return launch_tiled(bndm_scan<kBndmT, kBndmL, false>, a, tr, kBndmT, lds, 8, num_cus, stream);
         }
         case SMARTGPU_SO: {
             const size_t lds = 1040 + (size_t)kSoT * kSoL + 32;

@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsmartgpu.so")
+# SMARTGPU_LIB overrides the library path (A/B runs of two builds in one session)
+LIB_PATH = os.environ.get("SMARTGPU_LIB") or os.path.join(_HERE, "csrc", "libsmartgpu.so")
 ALGOS = ("hor", "bm", "kmp", "so", "bndm", "epsm")
 
 _lib = None

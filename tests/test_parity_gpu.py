@@ -68,6 +68,24 @@ def test_horspool_variants(oracle, variant):
         engine.tune(0, 0)
 
 
+def test_skip_loops_forced_for_short_patterns(oracle):
+    """m <= 16 normally goes to the packed matcher; force the LDS-tile skip loops of
+    BM and BNDM so that they stay covered for short patterns too."""
+    from smart_amd import engine
+    engine.tune(0, 1)
+    try:
+        for r in load_golden("fuzz_vectors.json")["rows"]:
+            if r["m"] > 17:
+                continue
+            P, T = fuzz_case(oracle, r)
+            text = Text.upload(T)
+            got = gpu_counts(P, text, algos=("bm", "bndm"))
+            text.free()
+            assert got["bm"] == r["count"] and got["bndm"] == r["count"], (r, got)
+    finally:
+        engine.tune(0, 0)
+
+
 def test_survey_vectors(oracle):
     g = load_golden("survey_vectors.json")
     texts = {}
