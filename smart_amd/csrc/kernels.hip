@@ -823,7 +823,9 @@ struct EpsmFp { uint32_t f0, f1, f2, f3, k0, k1, k2, k3, nd, m; };
 #define SG_W(x) (((x) & 3) == 0 ? d[(x) >> 2] \
                                 : __builtin_amdgcn_alignbyte(d[((x) >> 2) + 1], d[(x) >> 2], (x) & 3))
 
-template <bool VERIFY>  // VERIFY: m > 16, bytes 16.. are compared in memory
+// MODE 0: some fingerprint dword is partial (m < 16, m % 4 != 0) -> masked compares;
+// MODE 1: whole dwords only; MODE 2: m > 16, four whole dwords + bytes 16.. verified in memory
+template <int MODE>
 static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const EpsmFp& fp,
                                                     const uint4& A, const uint4& Bv, uint64_t p0,
                                                     uint32_t& pending)
@@ -838,8 +840,8 @@ static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const Eps
         const uint32_t hi = hi64 > 16 ? 16u : (uint32_t)hi64;
         cand = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
     }
-    // VERIFY (m > 16) implies four full fingerprint dwords: no byte masks needed
-#define SG_EQ(x, kk, ff) (VERIFY ? (SG_W(x) == (ff)) : ((SG_W(x) & (kk)) == (ff)))
+    constexpr bool VERIFY = MODE == 2;
+#define SG_EQ(x, kk, ff) (MODE != 0 ? (SG_W(x) == (ff)) : ((SG_W(x) & (kk)) == (ff)))
     const uint32_t nd = VERIFY ? 4u : fp.nd;
     {
         uint32_t eq = 0;
@@ -864,7 +866,7 @@ static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const Eps
         }
     }
 #undef SG_EQ
-    if (VERIFY) {  // the caller verifies bytes 16.. of the survivors (epsm_verify)
+    if (MODE == 2) {  // the caller verifies bytes 16.. of the survivors (epsm_verify)
         pending = cand;
         return 0;
     }
@@ -895,7 +897,7 @@ static __device__ __attribute__((noinline)) uint32_t epsm_verify(const uint8_t* 
 
 // ALGO only tags the instantiation (rocprofv3 shows packed_scan<256, 4, 5, ..> for
 // EPSM and packed_scan<256, 4, 0, ..> for Horspool's short-pattern regime).
-template <int THREADS, int ROWS, int ALGO, bool VERIFY>
+template <int THREADS, int ROWS, int ALGO, int MODE>
 __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_first,
                                                        uint64_t nrows)
 {
@@ -923,9 +925,9 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_
         for (int j = 0; j < ROWS; ++j) {
             pend[j] = 0;
             if (g + j < nrows)
-                hits += epsm_row<VERIFY>(a, fp, A[j], B[j], ((row_first + g + j) * THREADS + threadIdx.x) * 16, pend[j]);
+                hits += epsm_row<MODE>(a, fp, A[j], B[j], ((row_first + g + j) * THREADS + threadIdx.x) * 16, pend[j]);
         }
-        if (VERIFY) {
+        if (MODE == 2) {
             uint32_t any_pend = 0;
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) any_pend |= pend[j];
@@ -1095,13 +1097,19 @@ static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stre
     uint64_t grid = ((uint64_t)tr.count + rows - 1) / rows;
     const uint64_t cap = (uint64_t)num_cus * 8;
     if (grid > cap) grid = cap;
-#define SG_PACKED(R_, V_)                                                                          \
-    hipLaunchKernelGGL((packed_scan<kEpsmT, R_, ALGO, V_>), dim3((uint32_t)grid), dim3(kEpsmT), 0,   \
+#define SG_PACKED(R_, M_)                                                                          \
+    hipLaunchKernelGGL((packed_scan<kEpsmT, R_, ALGO, M_>), dim3((uint32_t)grid), dim3(kEpsmT), 0,   \
                        stream, a, tr.first, (uint64_t)tr.count)
-    const bool verify = a.m > 16;
-    if (rows == 1) { if (verify) SG_PACKED(1, true); else SG_PACKED(1, false); }
-    else if (rows == 2) { if (verify) SG_PACKED(2, true); else SG_PACKED(2, false); }
-    else { if (verify) SG_PACKED(4, true); else SG_PACKED(4, false); }
+#define SG_PACKED_ROWS(M_)                                                   \
+    do {                                                                     \
+        if (rows == 1) SG_PACKED(1, M_);                                     \
+        else if (rows == 2) SG_PACKED(2, M_);                                \
+        else SG_PACKED(4, M_);                                               \
+    } while (0)
+    if (a.m > 16) SG_PACKED_ROWS(2);
+    else if (a.m % 4 == 0) SG_PACKED_ROWS(1);
+    else SG_PACKED_ROWS(0);
+#undef SG_PACKED_ROWS
 #undef SG_PACKED
     return hipGetLastError();
 }
