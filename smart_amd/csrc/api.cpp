@@ -103,6 +103,7 @@ struct smartgpu_plan {
     int algo = 0;
     uint32_t m = 0;
     uint32_t halo = 0;
+    uint32_t prefer_packed = 0;  // see build_blob
     uint8_t* blob = nullptr;               // device: pattern + tables
     unsigned long long* results = nullptr; // device: kResultSlots counters (library-owned)
     unsigned long long* ext_results = nullptr; // caller-owned device buffer, if set
@@ -145,8 +146,10 @@ smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
 }
 
 // Build the device blob (pattern + tables) for (algo, P, m) in a host vector.
-std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t* halo)
+std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t* halo,
+                                uint32_t* prefer_packed)
 {
+    *prefer_packed = 0;
     std::vector<uint8_t> blob(sg::kPatternBytes, 0);
     std::memcpy(blob.data(), P, m);
     auto append = [&blob](const void* p, size_t bytes) {
@@ -164,6 +167,15 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         }
         append(fp, sizeof fp);
     };
+    // Mean bad-character shift if the text's symbols are distributed like the pattern's
+    // own.  Below ~6 bytes (binary / DNA-like alphabets) a skip loop verifies almost every
+    // window and lanes diverge; the packed matcher is the better regime there (measured
+    // on rand2/rand4).  The count does not depend on the choice.
+    auto tiny_shifts = [&](const std::vector<int32_t>& bc) {
+        uint64_t sum = 0;
+        for (uint32_t i = 0; i < m; ++i) sum += static_cast<uint64_t>(bc[P[i]]);
+        return m > 16 && sum < 6ull * m;
+    };
     *halo = std::min<uint32_t>(m - 1, sg::kHaloMax);
     switch (algo) {
         case SMARTGPU_HOR: {
@@ -175,7 +187,8 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             uint8_t tab8[256];  // plain u8 shifts for the bank-private kernel (m <= 255)
             for (int c = 0; c < 256; ++c) tab8[c] = static_cast<uint8_t>(bc[c] > 255 ? 255 : bc[c]);
             append(tab8, 256);
-            append_fingerprint();  // m <= 4 regime: packed compare of the whole window
+            append_fingerprint();  // packed regime
+            *prefer_packed = tiny_shifts(bc);
             break;
         }
         case SMARTGPU_BM: {
@@ -193,7 +206,8 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             tab[256 + m] = static_cast<uint16_t>(safe);
             append(tab.data(), tab.size() * 2);
             if (blob.size() % 4) blob.resize((blob.size() + 3) & ~size_t(3), 0);
-            append_fingerprint();  // m <= 8 regime
+            append_fingerprint();  // packed regime
+            *prefer_packed = tiny_shifts(bc);
             break;
         }
         case SMARTGPU_KMP: {
@@ -243,6 +257,7 @@ sg::ScanArgs make_args(const smartgpu_plan* p, const smartgpu_text* text, uint64
     a.m = p->m;
     a.halo = p->halo;
     a.fp_off = 0;
+    a.prefer_packed = p->prefer_packed;
     a.blob = p->blob;
     a.count = p->slot_ptr(slot);
     return a;
@@ -380,7 +395,7 @@ smartgpu_plan* smartgpu_plan_create(int algo, const uint8_t* P, uint32_t m, int 
     p->device = device;
     p->algo = algo;
     p->m = m;
-    const std::vector<uint8_t> blob = build_blob(algo, P, m, &p->halo);
+    const std::vector<uint8_t> blob = build_blob(algo, P, m, &p->halo, &p->prefer_packed);
     bool ok = hipMalloc(reinterpret_cast<void**>(&p->blob), blob.size()) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&p->results), sizeof(unsigned long long) * sg::kResultSlots) == hipSuccess;
     if (ok) {
@@ -456,7 +471,7 @@ int smartgpu_plan_result(smartgpu_plan* p, int slot, uint64_t* count, double* ke
 
 const char* smartgpu_plan_kernel_name(const smartgpu_plan* p)
 {
-    return p ? sg::scan_kernel_name(p->algo, p->m) : nullptr;
+    return p ? sg::scan_kernel_name(p->algo, p->m, p->prefer_packed != 0) : nullptr;
 }
 
 void* smartgpu_plan_result_device_ptr(smartgpu_plan* p) { return p ? p->slot_ptr(0) : nullptr; }

@@ -1070,14 +1070,15 @@ constexpr int kEpsmT = 256;
 
 static int hor_regime(uint32_t m);
 
-const char* scan_kernel_name(int algo, uint32_t m)
+const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
 {
+    const bool pk = prefer_packed && g_tune[0] == 0;
     switch (algo) {
         case SMARTGPU_HOR: {
-            const int r = hor_regime(m);
+            const int r = pk ? 3 : hor_regime(m);
             return r == 3 ? "packed_scan" : r == 2 ? "hor_scan_bp" : "hor_scan";
         }
-        case SMARTGPU_BM: return (m <= kPackedMaxM && g_tune[0] != 1) ? "packed_scan" : "bm_scan";
+        case SMARTGPU_BM: return (pk || (m <= kPackedMaxM && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return m <= 40 ? "kmp_scan" : "kmp_stream";
         case SMARTGPU_SO: return "so_scan";
         case SMARTGPU_BNDM: return (m <= kPackedMaxM && g_tune[0] != 1) ? "packed_scan" : "bndm_scan";
@@ -1124,7 +1125,7 @@ static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stre
 static int hor_regime(uint32_t m)
 {
     const int v = g_tune[0];  // 0 auto, 1 flat, 2 bank-private, 3 packed
-    if (v == 3) return m <= 16 ? 3 : 1;
+    if (v == 3) return 3;
     if (v == 2) return m <= 255 ? 2 : 1;
     if (v == 1) return 1;
     return m <= kPackedMaxM ? 3 : 1;  // bank-private kernel: only on request
@@ -1137,7 +1138,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
     switch (algo) {
         case SMARTGPU_HOR: {
             const uint32_t H = a.halo;
-            const int regime = hor_regime(m);
+            const int regime = (a.prefer_packed && g_tune[0] == 0) ? 3 : hor_regime(m);
             if (regime == 3) {
                 ScanArgs b = a;
                 b.fp_off = kTableOff + 768;  // fingerprint sits after the u16 and u8 tables
@@ -1154,7 +1155,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             return launch_tiled(hor_scan<kHorT, kHorL, false>, a, tr, kHorT, lds, 8, num_cus, stream);
         }
         case SMARTGPU_BM: {
-            if (m <= kPackedMaxM && g_tune[0] != 1) {
+            if ((m <= kPackedMaxM && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
                 ScanArgs b = a;
                 b.fp_off = kTableOff + ((512 + 2 * (m + 1) + 3) & ~3u);  // after bc, gs, safe shift
                 return launch_packed<SMARTGPU_BM>(b, num_cus, stream);

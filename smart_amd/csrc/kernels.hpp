@@ -26,6 +26,7 @@ struct ScanArgs {
     uint32_t m;                 // pattern length
     uint32_t halo;              // skip kernels: back-halo H = min(m-1, kHaloMax); serial: forward halo
     uint32_t fp_off;            // packed kernel: blob offset of the fingerprint (set by launch_scan)
+    uint32_t prefer_packed;     // HOR/BM: the shift tables promise tiny shifts (small alphabet) -> packed regime
     const uint8_t* blob;        // device: [pattern kPatternBytes][tables ...]
     unsigned long long* count;  // device result slot (pre-zeroed)
 };
@@ -45,7 +46,7 @@ struct LaunchInfo {
 
 // Enqueue the scan for `algo` on `stream`; returns hipSuccess or the launch error.
 hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream);
-const char* scan_kernel_name(int algo, uint32_t m);
+const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed);
 
 // tuning knobs (smartgpu_tune): [0] HOR variant 0 auto / 1 flat / 2 bank-private
 extern int g_tune[8];
