@@ -18,10 +18,10 @@
 //     atomic per wave goes to the result slot.
 //
 // Skip kernels (HOR, BM, BNDM) index tiles by window END position e = s+m-1 and
-// keep a BACK halo of H = min(m-1, 256) bytes in LDS: the byte that drives the
-// shift, T[e], is always in the tile, verification runs right-to-left through
-// the halo and — only for m-1 > H and only after H+1 bytes matched — continues
-// in global memory.  Serial kernels (SO, KMP) index tiles by START position and
+// keep a BACK halo of H = min(m-1, 16) bytes in LDS: the byte that drives the
+// shift, T[e], is always in the tile; a lane verifies right-to-left through the
+// halo by itself and — only for m-1 > H and only after H+1 bytes matched — parks
+// the window for a wave-cooperative comparison of the rest (wave_verify).  Serial kernels (SO, KMP) index tiles by START position and
 // keep a forward halo.
 #include "kernels.hpp"
 
@@ -69,20 +69,34 @@ __device__ __forceinline__ void flush_hits(uint32_t lane_hits, unsigned long lon
     if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(out, v);
 }
 
-// Equality of `len` bytes in memory, 16 bytes per step (gfx950 global loads may be
-// unaligned: an align-1 16-byte copy compiles to one global_load_dwordx4).
+// 16 bytes at a (text, any alignment) vs 16 bytes at b (pattern slot), first `nb`
+// bytes only (1 <= nb <= 16).  Both reads stay in bounds by construction: the text
+// buffer has a back pad and the pattern slot of the blob is 4224 zero-padded bytes.
+// (gfx950 global loads may be unaligned: an align-1 16-byte copy compiles to one
+// global_load_dwordx4.)
+__device__ __forceinline__ bool differ16(const uint8_t* __restrict__ a,
+                                         const uint8_t* __restrict__ b, uint32_t nb)
+{
+    uint4 x, y;
+    __builtin_memcpy(&x, a, 16);
+    __builtin_memcpy(&y, b, 16);
+    const uint32_t d[4] = {x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w};
+    uint32_t acc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int left = (int)nb - 4 * q;  // bytes of dword q that count
+        const uint32_t mask = left >= 4 ? 0xFFFFFFFFu : left <= 0 ? 0u : (0xFFFFFFFFu >> (8 * (4 - left)));
+        acc |= d[q] & mask;
+    }
+    return acc != 0;
+}
+
+// Equality of `len` bytes in memory, 16 bytes per step.
 __device__ __forceinline__ bool global_equal(const uint8_t* __restrict__ a,
                                              const uint8_t* __restrict__ b, uint32_t len)
 {
-    uint32_t i = 0;
-    for (; i + 16 <= len; i += 16) {
-        uint4 x, y;
-        __builtin_memcpy(&x, a + i, 16);
-        __builtin_memcpy(&y, b + i, 16);
-        if ((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) return false;
-    }
-    for (; i < len; ++i)
-        if (a[i] != b[i]) return false;
+    for (uint32_t i = 0; i < len; i += 16)
+        if (differ16(a + i, b + i, len - i < 16 ? len - i : 16u)) return false;
     return true;
 }
 
@@ -106,16 +120,8 @@ __device__ __forceinline__ uint32_t wave_verify(bool has, const uint8_t* tptr,
         const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(tp >> 32), src);
         const uint8_t* t = reinterpret_cast<const uint8_t*>(((unsigned long long)hi << 32) | lo);
         bool diff = false;
-        for (uint32_t off = lane * 16u; off < len; off += 1024u) {
-            if (off + 16u <= len) {
-                uint4 x, y;
-                __builtin_memcpy(&x, t + off, 16);
-                __builtin_memcpy(&y, pptr + off, 16);
-                diff |= ((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) != 0;
-            } else {
-                for (uint32_t i = off; i < len; ++i) diff |= t[i] != pptr[i];
-            }
-        }
+        for (uint32_t off = lane * 16u; off < len; off += 1024u)
+            diff |= differ16(t + off, pptr + off, len - off < 16 ? len - off : 16u);
         if (!__any(diff) && lane == (uint32_t)src) mine = 1;
     }
     return mine;
@@ -1126,7 +1132,7 @@ static int hor_regime(uint32_t m)
 {
     const int v = g_tune[0];  // 0 auto, 1 flat, 2 bank-private, 3 packed
     if (v == 3) return 3;
-    if (v == 2) return m <= 255 ? 2 : 1;
+    if (v == 2) return m <= kHaloMax + 1 ? 2 : 1;  // the bank-private kernel keeps whole windows in LDS
     if (v == 1) return 1;
     return m <= kPackedMaxM ? 3 : 1;  // bank-private kernel: only on request
 }

@@ -32,12 +32,18 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--json", default=None)
     ap.add_argument("--tune", default="", help="comma list key=value passed to smartgpu_tune")
+    ap.add_argument("--corpus", default="rand", help="rand (counter-based rand<sigma>) or english "
+                    "(tests/golden/english_excerpt.txt replicated to --gib, BASELINE config 4 style)")
     args = ap.parse_args()
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         smart_amd.engine.tune(int(k), int(v))
     n = int(args.gib * (1 << 30))
-    text = Text.generate(SEED, args.sigma, n)
+    if args.corpus == "english":
+        unit = np.fromfile(os.path.join(ROOT, "tests", "golden", "english_excerpt.txt"), dtype=np.uint8)
+        text = Text.upload_tiled(unit, n)
+    else:
+        text = Text.generate(SEED, args.sigma, n)
     print("streaming-read probe: %.1f GB/s" % smart_amd.engine.probe_read_gbs(text), flush=True)
     rows = []
     for m in [int(x) for x in args.ms.split(",")]:
