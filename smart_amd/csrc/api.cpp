@@ -216,6 +216,11 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             for (uint32_t i = 0; i <= m; ++i) tab[i] = static_cast<int16_t>(nx[i]);
             append(tab.data(), tab.size() * 2);
             *halo = m - 1;  // forward halo: the automaton re-scans m-1 bytes
+            if (m <= sg::kKmpDfaMaxM) {  // transition table for kmp_runs<true>, 16-byte aligned
+                blob.resize((blob.size() + 15) & ~size_t(15), 0);
+                const std::vector<uint8_t> dfa = sg::kmp_dfa(P, m);
+                append(dfa.data(), dfa.size());
+            }
             break;
         }
         case SMARTGPU_SO: {

@@ -759,51 +759,134 @@ __global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a, uint64_t tile_fi
     flush_hits(hits, a.count);
 }
 
-// Streaming variant for m > 40: no LDS text tile; each lane streams its own run
-// of `seg_len` start positions straight from memory, 16 bytes per load with the
-// next chunk prefetched.  64 lanes x 16 B from 64 different lines per wave-load
-// is a poor access pattern (it tops out near 1.1 TB/s even with no automaton
-// work), but a lane's run can be as long as the re-scan of m-1 bytes requires,
-// which LDS tiles cannot offer at useful occupancy.
-__global__ __launch_bounds__(256) void kmp_stream(ScanArgs a, uint32_t seg_len, uint64_t nsegs)
+// KMP over per-lane RUNS streamed through LDS (m > 40, and every m <= 95 via the
+// transition table).  A lane owns a run of `run_len` start positions (any length:
+// the host picks it from m so that the re-scan of m-1 bytes is bounded), but a
+// lane-private stream is a terrible access pattern (64 lanes x 16 B from 64
+// different lines per wave-load: 1.1 TB/s measured even with no automaton work).
+// So the WAVE moves the data: per step it fetches the next 64 bytes of each of its
+// 64 runs with four coalesced wave-loads (4 lanes cover one run's 64-byte sector),
+// parks them in its own LDS slab [run][80 B] (stride 5*16 B: odd, so the lanes'
+// ds_read_b128 hit distinct bank groups) and each lane then reads its run's 64
+// bytes back.  No workgroup barrier: a wave's DS operations execute in order.
+// The next step's loads are issued before the current step is processed.
+//
+// DFA = true (m <= 95): the failure function is expanded on the host into the
+// automaton's transition table delta[s][c] (u8, (m+1)*256 B in LDS), so a text byte
+// costs ONE dependent LDS lookup, no data-dependent loop: st = delta[st][c].
+// DFA = false: failure links (kmp_chunk above).
+constexpr int kRunSlab = 64 * 80;  // LDS bytes per wave
+
+template <bool CHECK>
+__device__ __forceinline__ void kmp_dfa_chunk(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
+                                              uint32_t& st, uint32_t& hits, uint32_t m,
+                                              const uint8_t* __restrict__ dfa)
+{
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+        const uint32_t nx = dfa[(st << 8) | c];
+        if (CHECK) {
+            const uint32_t j = j_base + q;
+            const bool live = j >= j0 && j < jend;
+            st = live ? nx : st;
+            hits += live && nx == m;
+        } else {
+            st = nx;
+            hits += nx == m;
+        }
+    }
+}
+
+template <bool DFA>
+__global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
+                                                uint32_t dfa_off)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int m = (int)a.m;
-    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
+    const uint32_t m = a.m;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // LDS: [table][4 wave slabs]
+    const uint32_t table_bytes = DFA ? round16((m + 1) * 256) : round16(4 * m);
+    uint8_t* slab = smem + table_bytes + wave * kRunSlab;
     const int16_t* gnext = reinterpret_cast<const int16_t*>(a.blob + kTableOff);
-    for (uint32_t i = threadIdx.x; i < (uint32_t)m; i += 256)
-        tab[i] = ((uint32_t)a.blob[i] << 16) | (uint16_t)gnext[i];
-    __syncthreads();
+    if (DFA) {
+        const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
+        uint4* t = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = threadIdx.x; i < (m + 1) * 16; i += 256) t[i] = g[i];
+    } else {
+        uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
+        for (uint32_t i = threadIdx.x; i < m; i += 256)
+            tab[i] = ((uint32_t)a.blob[i] << 16) | (uint16_t)gnext[i];
+    }
+    __syncthreads();  // the only workgroup barrier: tables visible
+    const uint8_t* dfa = smem;
+    const uint32_t* tab = reinterpret_cast<const uint32_t*>(smem);
     const uint32_t p0 = a.blob[0];
     const int next_m = gnext[m];
 
     uint32_t hits = 0;
-    const uint64_t nthreads = (uint64_t)gridDim.x * 256;
-    // runs are cut on absolute offsets (multiples of seg_len, itself a multiple of 16)
-    const uint64_t seg_first = a.s_begin / seg_len;
-    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < nsegs; g += nthreads) {
-        const uint64_t seg = (seg_first + g) * seg_len;
+    const uint64_t run_first = a.s_begin / run_len;  // runs are cut on absolute offsets
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint32_t span = run_len + m - 1;           // bytes a run scans
+    const uint32_t nsteps = (span + 63) / 64;
+    // group = 64 consecutive runs handled by one wave
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g * 64 < nruns; g += nwaves) {
+        // loader role: lane covers piece (lane & 3) of runs 16*i + (lane >> 2), i = 0..3
+        const uint8_t* src[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint64_t r = g * 64 + 16 * i + (lane >> 2);
+            if (r >= nruns) r = nruns - 1;  // clamp: loaded but never consumed
+            src[i] = a.text + (run_first + r) * run_len + (lane & 3u) * 16u;
+        }
+        // owner role: this lane's run and the bytes of it that count
+        const uint64_t my = g * 64 + lane;
+        const uint64_t seg = (run_first + my) * run_len;
         const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
-        const uint64_t sb = seg + seg_len < a.s_end ? seg + seg_len : a.s_end;
-        if (sa >= sb) continue;
-        const uint8_t* base = a.text + seg;  // 16-byte aligned
-        const uint32_t j0 = (uint32_t)(sa - seg);
-        const uint32_t jend = (uint32_t)(sb - seg) + (uint32_t)m - 1;
-        uint32_t j = j0 & ~15u;
-        uint4 cur = *reinterpret_cast<const uint4*>(base + j);
-        int st = 0;
-        if (j < j0 || j + 16 > jend) {
-            kmp_chunk<true>(cur, j, j0, jend, st, hits, m, p0, next_m, tab);
-            j += 16;
-            if (j < jend) cur = *reinterpret_cast<const uint4*>(base + j);
+        const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
+        const bool owner = my < nruns && sa < sb;
+        const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
+        const uint32_t jend = owner ? (uint32_t)(sb - seg) + m - 1 : 0u;
+
+        uint4 nx0 = *reinterpret_cast<const uint4*>(src[0]);
+        uint4 nx1 = *reinterpret_cast<const uint4*>(src[1]);
+        uint4 nx2 = *reinterpret_cast<const uint4*>(src[2]);
+        uint4 nx3 = *reinterpret_cast<const uint4*>(src[3]);
+        uint32_t st = 0;
+        int sti = 0;
+        for (uint32_t k = 0; k < nsteps; ++k) {
+            // park this step's 64 bytes of every run in the slab
+            {
+                uint8_t* dst = slab + (lane >> 2) * 80u + (lane & 3u) * 16u;
+                *reinterpret_cast<uint4*>(dst) = nx0;
+                *reinterpret_cast<uint4*>(dst + 16 * 80) = nx1;
+                *reinterpret_cast<uint4*>(dst + 32 * 80) = nx2;
+                *reinterpret_cast<uint4*>(dst + 48 * 80) = nx3;
+            }
+            if (k + 1 < nsteps) {  // prefetch the next step (wave-uniform)
+                const uint32_t o = (k + 1) * 64u;
+                nx0 = *reinterpret_cast<const uint4*>(src[0] + o);
+                nx1 = *reinterpret_cast<const uint4*>(src[1] + o);
+                nx2 = *reinterpret_cast<const uint4*>(src[2] + o);
+                nx3 = *reinterpret_cast<const uint4*>(src[3] + o);
+            }
+            const uint32_t jb = k * 64u;
+            const uint8_t* mine = slab + lane * 80u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = *reinterpret_cast<const uint4*>(mine + 16 * q);
+                const uint32_t j = jb + 16u * q;
+                const bool full = j >= j0 && j + 16 <= jend;
+                if (DFA) {
+                    if (full) kmp_dfa_chunk<false>(v, j, j0, jend, st, hits, m, dfa);
+                    else if (j < jend && j + 16 > j0) kmp_dfa_chunk<true>(v, j, j0, jend, st, hits, m, dfa);
+                } else {
+                    if (full) kmp_chunk<false>(v, j, j0, jend, sti, hits, (int)m, p0, next_m, tab);
+                    else if (j < jend && j + 16 > j0) kmp_chunk<true>(v, j, j0, jend, sti, hits, (int)m, p0, next_m, tab);
+                }
+            }
         }
-        while (j + 16 <= jend) {
-            const uint4 nxt = *reinterpret_cast<const uint4*>(base + j + 16);  // in the back pad at worst
-            kmp_chunk<false>(cur, j, j0, jend, st, hits, m, p0, next_m, tab);
-            cur = nxt;
-            j += 16;
-        }
-        if (j < jend) kmp_chunk<true>(cur, j, j0, jend, st, hits, m, p0, next_m, tab);
     }
     flush_hits(hits, a.count);
 }
@@ -1085,12 +1168,42 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
             return r == 3 ? "packed_scan" : r == 2 ? "hor_scan_bp" : "hor_scan";
         }
         case SMARTGPU_BM: return (pk || (m <= kPackedMaxM && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
-        case SMARTGPU_KMP: return m <= 40 ? "kmp_scan" : "kmp_stream";
+        case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : "kmp_runs";
         case SMARTGPU_SO: return "so_scan";
         case SMARTGPU_BNDM: return (m <= kPackedMaxM && g_tune[0] != 1) ? "packed_scan" : "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
     }
     return "?";
+}
+
+// KMP runs.  Run length: re-scan overhead (m-1)/L <= 1/8 when the text is long enough,
+// never above 1/2, short enough to give every CU ~16 waves of runs, multiple of 64.
+static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream)
+{
+    const uint32_t m = a.m;
+    const uint64_t span = a.s_end - a.s_begin;
+    uint64_t L = 8ull * (m - 1);
+    const uint64_t fill = span / ((uint64_t)num_cus * 16 * 64);
+    if (L > fill) L = fill;
+    if (L < 2ull * (m - 1)) L = 2ull * (m - 1);
+    if (L < 256) L = 256;
+    L = (L + 63) & ~63ull;
+    const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
+    if (tr.count == 0) return hipSuccess;
+    const bool dfa = m <= kKmpDfaMaxM;
+    const size_t table = dfa ? r16((m + 1) * 256) : r16(4 * m);
+    const size_t lds = table + 4 * (size_t)kRunSlab;
+    uint64_t grid = ((uint64_t)tr.count + 255) / 256;
+    const uint64_t cap = (uint64_t)num_cus * 4;
+    if (grid > cap) grid = cap;
+    const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));
+    if (dfa)
+        hipLaunchKernelGGL(kmp_runs<true>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
+                           (uint64_t)tr.count, dfa_off);
+    else
+        hipLaunchKernelGGL(kmp_runs<false>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
+                           (uint64_t)tr.count, dfa_off);
+    return hipGetLastError();
 }
 
 // The packed matcher; `a.blob` must carry the fingerprint at kTableOff (EPSM
@@ -1202,27 +1315,13 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
         const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)(T_) * (L_));            \
         return launch_tiled(kmp_scan<T_, L_>, a, tr, T_, lds, WGS_, num_cus, stream);          \
     } while (0)
-            if (m <= 16) SG_KMP(256, 80, 6);
-            if (m <= 40) SG_KMP(256, 144, 4);
+            if (g_tune[3] == 1) {  // LDS-tile kernel (failure links), for A/B
+                if (m <= 16) SG_KMP(256, 80, 6);
+                if (m <= 40) SG_KMP(256, 144, 4);
+            }
 #undef SG_KMP
-            // m > 40: per-lane streaming runs (see kmp_stream); run length: re-scan overhead
-            // (m-1)/L <= 1/8 when the text is long enough, never above 1/2, and short enough
-            // to give every CU ~16 waves of runs
-            const uint64_t span = a.s_end - a.s_begin;
-            uint64_t L = 8ull * (m - 1);
-            const uint64_t fill = span / ((uint64_t)num_cus * 16 * 64);
-            if (L > fill) L = fill;
-            if (L < 2ull * (m - 1)) L = 2ull * (m - 1);
-            if (L < 256) L = 256;
-            L = (L + 15) & ~15ull;
-            const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
-            if (tr.count == 0) return hipSuccess;
-            uint64_t grid = ((uint64_t)tr.count + 255) / 256;
-            const uint64_t cap = (uint64_t)num_cus * 8;
-            if (grid > cap) grid = cap;
-            hipLaunchKernelGGL(kmp_stream, dim3((uint32_t)grid), dim3(256), r16(4 * m), stream, a, (uint32_t)L,
-                               (uint64_t)tr.count);
-            return hipGetLastError();
+            // per-lane runs streamed through LDS (kmp_runs)
+            return launch_kmp_runs(a, num_cus, stream);
         }
         case SMARTGPU_EPSM: {
             ScanArgs b = a;

@@ -18,6 +18,7 @@ constexpr uint64_t kBackPad = 160 * 1024;       // >= largest tile + kXSize + 64
 constexpr uint32_t kHaloMax = 16;               // bytes a lane verifies by itself in LDS before it parks the window
 constexpr uint32_t kPatternBytes = 4224;        // pattern slot in the plan blob (>= kXSize, /16)
 constexpr int kResultSlots = 4096;
+constexpr uint32_t kKmpDfaMaxM = 95;            // KMP: (m+1)*256-byte transition table kept in LDS up to this m
 
 // What every scan kernel receives.
 struct ScanArgs {
@@ -34,7 +35,7 @@ struct ScanArgs {
 // Byte offsets of the tables inside the blob, after the pattern slot.
 //  HOR : u16 tab[256]   shift | 0x8000 if c == P[m-1]; u8 tab8[256]; fingerprint (as EPSM)
 //  BM  : u16 bc[256], u16 gs[m], u16 safe_shift
-//  KMP : i16 next[m+1]
+//  KMP : i16 next[m+1]; for m <= kKmpDfaMaxM also u8 dfa[(m+1)*256] (16-byte aligned)
 //  SO  : u32 S[256]
 //  BNDM: u32 B[256]
 //  EPSM: u32 fp[4], u32 fpmask[4]   (first min(m,16) pattern bytes as dwords + byte masks)

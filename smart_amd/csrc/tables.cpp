@@ -72,6 +72,28 @@ std::vector<int32_t> kmp_next(const uint8_t* P, uint32_t m)
     return next;
 }
 
+std::vector<uint8_t> kmp_dfa(const uint8_t* P, uint32_t m)
+{
+    // border[s] = longest proper border of P[0..s); delta(s,c) = s+1 on a match,
+    // otherwise delta(border[s], c) — the failure links followed once and for all
+    std::vector<int32_t> border(m + 1, 0);
+    border[0] = -1;
+    int32_t b = -1;
+    for (uint32_t i = 0; i < m; ++i) {
+        while (b >= 0 && P[i] != P[b]) b = border[b];
+        border[i + 1] = ++b;
+    }
+    std::vector<uint8_t> dfa(static_cast<size_t>(m + 1) * 256, 0);
+    dfa[P[0]] = 1;
+    for (uint32_t s = 1; s <= m; ++s) {
+        const uint8_t* from = &dfa[static_cast<size_t>(border[s]) * 256];
+        uint8_t* row = &dfa[static_cast<size_t>(s) * 256];
+        for (int c = 0; c < 256; ++c) row[c] = from[c];
+        if (s < m) row[P[s]] = static_cast<uint8_t>(s + 1);
+    }
+    return dfa;
+}
+
 std::vector<uint32_t> shift_or_masks(const uint8_t* P, uint32_t m)
 {
     const uint32_t w = std::min<uint32_t>(m, 32);

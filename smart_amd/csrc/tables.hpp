@@ -23,6 +23,11 @@ std::vector<int32_t> good_suffix(const uint8_t* P, uint32_t m);
 // KMP strong failure links next[0..m] (kmp.c:27-41), next[0] = -1.
 std::vector<int32_t> kmp_next(const uint8_t* P, uint32_t m);
 
+// KMP automaton (the failure function expanded into the transition table, Knuth-Morris-
+// Pratt's delta): dfa[s*256 + c] = state after reading c in state s, states 0..m (m <= 255),
+// state m = "an occurrence ends here".  (m+1)*256 bytes.
+std::vector<uint8_t> kmp_dfa(const uint8_t* P, uint32_t m);
+
 // Shift-Or: S[c] has bit i clear iff P[i]==c, over the first w=min(m,32) bytes
 // (so.c:27-38,73-74).  The hit test "D < lim" (so.c:56) is "bit w-1 of D is 0".
 std::vector<uint32_t> shift_or_masks(const uint8_t* P, uint32_t m);
