@@ -1186,7 +1186,8 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     const uint64_t fill = span / ((uint64_t)num_cus * 16 * 64);
     if (L > fill) L = fill;
     if (L < 2ull * (m - 1)) L = 2ull * (m - 1);
-    if (L < 256) L = 256;
+    const uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 512;  // longer runs amortise the per-run set-up
+    if (L < lmin) L = lmin;
     L = (L + 63) & ~63ull;
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
@@ -1194,7 +1195,7 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     const size_t table = dfa ? r16((m + 1) * 256) : r16(4 * m);
     const size_t lds = table + 4 * (size_t)kRunSlab;
     uint64_t grid = ((uint64_t)tr.count + 255) / 256;
-    const uint64_t cap = (uint64_t)num_cus * 4;
+    const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 4);
     if (grid > cap) grid = cap;
     const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));
     if (dfa)
