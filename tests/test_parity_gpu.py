@@ -242,3 +242,23 @@ def test_full_size_properties(oracle):
         want = oracle.search("hor", P, sl)
         for a in ("hor", "epsm", "so"):
             assert smart_amd.search(a, P, text, off=lo, n=32 << 20)[0] == want, (a, m)
+
+
+def test_text_beyond_4gib():
+    """64-bit offsets: a 5 GiB text (BASELINE configs 4-5 put 4 GiB on each GPU),
+    patterns cut at the very end, on both sides of 2^32 and at the start; the six
+    kernels must agree, find the planted occurrence, and a sub-range straddling
+    2^32 must see exactly the occurrences inside it."""
+    n = 5 * (1 << 30) + 12345
+    text = Text.generate(SEED2, 128, n)
+    lo, ln = (1 << 32) - 100000, 200000
+    for m in (4, 40, 4096):
+        for k in (n - m, (1 << 32) - 5, (1 << 32) + 11, 17):
+            P = text.pattern(k, m)
+            got = gpu_counts(P, text)
+            assert len(set(got.values())) == 1 and got["hor"] >= 1, (m, k, got)
+            sub = gpu_counts(P, text, algos=("hor", "kmp", "so", "epsm"), off=lo, n=ln)
+            inside = 1 if (lo <= k and k + m <= lo + ln) else 0
+            assert len(set(sub.values())) == 1 and sub["hor"] >= inside, (m, k, sub)
+            if m >= 40:
+                assert sub["hor"] == inside, (m, k, sub)
