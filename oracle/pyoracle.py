@@ -24,7 +24,7 @@ def build(ref=None):
     if ref is None:
         ref = os.path.isdir("/root/reference/src/algos")
     if ref:
-        targets.append("ref")
+        targets += ["ref", "refbin"]
     subprocess.check_call(["make", "-s", "-C", HERE] + targets)
 
 

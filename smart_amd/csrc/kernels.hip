@@ -891,6 +891,116 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
     flush_hits(hits, a.count);
 }
 
+// Shift-Or over per-lane RUNS (the structure of kmp_runs below): with LDS tiles a
+// lane's run is 80 bytes and the w-1 bytes it re-scans to rebuild the state cost up
+// to 39 % extra work per owned byte (the kernel is VALU-bound: rocprofv3 shows 76 %
+// VALU busy); runs of 1 KiB make that 3 %.  Same recurrence as so_scan.
+template <bool LONG>
+__global__ __launch_bounds__(256) void so_runs(ScanArgs a, uint32_t run_len, uint64_t nruns)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m, w = m < 32 ? m : 32;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* S = reinterpret_cast<uint32_t*>(smem);  // 257 entries, padded to 1040 B
+    uint8_t* slab = smem + 1040 + wave * kRunSlab;
+    for (uint32_t i = threadIdx.x; i < 257; i += 256)
+        S[i] = (i < 256 ? reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] : 0xFFFFFFFFu) << (32 - w);
+    __syncthreads();  // the only workgroup barrier: table visible
+
+    uint32_t hits = 0;
+    const uint64_t run_first = a.s_begin / run_len;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint32_t nsteps = (run_len + w - 1 + 63) / 64;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g * 64 < nruns; g += nwaves) {
+        const uint8_t* src[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint64_t r = g * 64 + 16 * i + (lane >> 2);
+            if (r >= nruns) r = nruns - 1;  // clamp: loaded but never consumed
+            src[i] = a.text + (run_first + r) * run_len + (lane & 3u) * 16u;
+        }
+        const uint64_t my = g * 64 + lane;
+        const uint64_t seg = (run_first + my) * run_len;
+        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
+        const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
+        const bool owner = my < nruns && sa < sb;
+        const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
+        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
+
+        uint4 nx0 = *reinterpret_cast<const uint4*>(src[0]);
+        uint4 nx1 = *reinterpret_cast<const uint4*>(src[1]);
+        uint4 nx2 = *reinterpret_cast<const uint4*>(src[2]);
+        uint4 nx3 = *reinterpret_cast<const uint4*>(src[3]);
+        uint32_t D = 0xFFFFFFFFu << (32 - w);
+        bool parked = false;
+        const uint8_t* parked_at = a.text;
+        for (uint32_t k = 0; k < nsteps; ++k) {
+            {
+                uint8_t* dst = slab + (lane >> 2) * 80u + (lane & 3u) * 16u;
+                *reinterpret_cast<uint4*>(dst) = nx0;
+                *reinterpret_cast<uint4*>(dst + 16 * 80) = nx1;
+                *reinterpret_cast<uint4*>(dst + 32 * 80) = nx2;
+                *reinterpret_cast<uint4*>(dst + 48 * 80) = nx3;
+            }
+            if (k + 1 < nsteps) {
+                const uint32_t o = (k + 1) * 64u;
+                nx0 = *reinterpret_cast<const uint4*>(src[0] + o);
+                nx1 = *reinterpret_cast<const uint4*>(src[1] + o);
+                nx2 = *reinterpret_cast<const uint4*>(src[2] + o);
+                nx3 = *reinterpret_cast<const uint4*>(src[3] + o);
+            }
+            const uint8_t* mine = slab + lane * 80u;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const uint32_t base = k * 64u + 16u * c4;
+                if (base >= jend || base + 16 <= j0) continue;
+                const uint4 v = *reinterpret_cast<const uint4*>(mine + 16 * c4);
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+                const bool full = base >= j0 && base + 16 <= jend;
+                uint32_t sv[16];
+                if (full) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) sv[q] = S[(d[q >> 2] >> (8 * (q & 3))) & 0xFFu];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const uint32_t j = base + q;
+                        const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+                        sv[q] = S[(j >= j0 && j < jend) ? c : 256u];
+                    }
+                }
+                uint32_t H = 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    D = (D << 1) | sv[q];                     // so.c:55
+                    H = __builtin_amdgcn_alignbit(H, D, 31);  // so.c:56: sign bit clear <=> hit
+                }
+                uint32_t hm = ~H & 0xFFFFu;
+                if (!LONG) {
+                    hits += __popc(hm);
+                } else {
+                    while (hm) {  // 32-byte prefix matched, ending at byte q: verify P[32..m)
+                        const uint32_t bit = 31u - __builtin_clz(hm);
+                        hm &= ~(1u << bit);
+                        const uint8_t* rest = a.text + seg + base + (15u - bit) + 1;
+                        if (!parked) {
+                            parked = true;
+                            parked_at = rest;
+                        } else {
+                            hits += global_equal(rest, a.blob + w, m - w);
+                        }
+                    }
+                }
+            }
+            if (LONG && __any(parked)) {  // keep at most one parked window per lane
+                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
+                parked = false;
+            }
+        }
+    }
+    flush_hits(hits, a.count);
+}
+
 // ---------------------------------------------------------------------------
 // EPSM — packed matching  (reference: src/algos/epsm.c; its SSE regimes —
 // broadcast compare, mpsadbw 4-byte filter, hashed 8-byte blocks — map to one
@@ -1169,7 +1279,7 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
         }
         case SMARTGPU_BM: return (pk || (m <= kPackedMaxM && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : "kmp_runs";
-        case SMARTGPU_SO: return "so_scan";
+        case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : "so_runs";
         case SMARTGPU_BNDM: return (m <= kPackedMaxM && g_tune[0] != 1) ? "packed_scan" : "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
     }
@@ -1299,6 +1409,24 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             return launch_tiled(bndm_scan<kBndmT, kBndmL, false>, a, tr, kBndmT, lds, 8, num_cus, stream);
         }
         case SMARTGPU_SO: {
+            if (g_tune[6] != 1) {  // per-lane runs through LDS slabs (tune[6]=1: LDS tiles, for A/B)
+                uint64_t L = g_tune[5] ? (uint64_t)g_tune[5] : 1024;
+                const uint64_t fill = (a.s_end - a.s_begin) / ((uint64_t)num_cus * 16 * 64);
+                if (L > fill) L = fill;
+                if (L < 256) L = 256;
+                L = (L + 63) & ~63ull;
+                const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
+                if (tr.count == 0) return hipSuccess;
+                uint64_t grid = ((uint64_t)tr.count + 255) / 256;
+                const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 6);
+                if (grid > cap) grid = cap;
+                const size_t lds = 1040 + 4 * (size_t)kRunSlab;
+                if (m > 32)
+                    hipLaunchKernelGGL(so_runs<true>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                else
+                    hipLaunchKernelGGL(so_runs<false>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                return hipGetLastError();
+            }
             const size_t lds = 1040 + (size_t)kSoT * kSoL + 32;
             const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kSoT * kSoL);
             if (m > 32) return launch_tiled(so_scan<kSoT, kSoL, true>, a, tr, kSoT, lds, 6, num_cus, stream);

@@ -1,0 +1,87 @@
+/*
+ * plugin_main — SMART's per-algorithm executable, backed by the MI355X engine.
+ *
+ * Speaks the process-level plugin protocol of the reference harness unchanged
+ * (reference: src/algos/include/main.h:42-136, spawned by src/smart.c:140-146 and
+ * src/test.c:67-74):
+ *
+ *     <algo> shared <pkey> <m> <tkey> <n> <rkey> <ekey> <prekey>
+ *
+ * attaches the five SysV segments (pattern, text, int result, double run time,
+ * double preprocessing time), runs the search, writes the count and the two times
+ * (ms) back, exits 0; any failure exits 1, which the harness records as -1
+ * (smart.c:143-145).  The non-shared form `<algo> P m T n` prints the count
+ * (main.h:123-135; the reference segfaults there).
+ *
+ * One binary per algorithm, selected at compile time with -DSMARTGPU_ALGO=<id>
+ * (smart_amd/host/Makefile builds bin/plugins/{hor,bm,kmp,so,bndm,epsm}), so an
+ * unmodified SMART `smart` / `test` finds them as source/bin/<algo>.
+ * Every spawn pays HIP initialisation and an n-byte upload: this is plumbing
+ * compatibility, not the fast path.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/ipc.h>
+#include <sys/shm.h>
+#include <sys/types.h>
+
+#include "smartgpu.h"
+
+#ifndef SMARTGPU_ALGO
+#error "compile with -DSMARTGPU_ALGO=<algorithm id>"
+#endif
+
+static void *attach(key_t key, size_t size)
+{
+    int id = shmget(key, size, 0666);
+    if (id < 0) { perror("shmget"); return NULL; }
+    void *p = shmat(id, NULL, 0);
+    if (p == (void *)-1) { perror("shmat"); return NULL; }
+    return p;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && !strcmp(argv[1], "shared")) {
+        if (argc < 9) {
+            printf("error in input parameter\nfive parameters needed when used with shared memory\n");
+            return 1;
+        }
+        const int m = atoi(argv[3]), n = atoi(argv[5]);
+        unsigned char *p = attach((key_t)atoi(argv[2]), (size_t)m);
+        unsigned char *t = attach((key_t)atoi(argv[4]), (size_t)n);
+        int *result = attach((key_t)atoi(argv[6]), 4);
+        double *run_time = attach((key_t)atoi(argv[7]), 8);
+        double *pre_time = attach((key_t)atoi(argv[8]), 8);
+        if (!p || !t || !result || !run_time || !pre_time) return 1;
+
+        smartgpu_text *text = smartgpu_text_upload(t, (uint64_t)n, 0);
+        if (!text) { fprintf(stderr, "%s\n", smartgpu_last_error()); return 1; }
+        uint64_t count = 0;
+        double pre_ms = 0, run_ms = 0;
+        int rc = smartgpu_search64(SMARTGPU_ALGO, p, (uint32_t)m, text, 0, (uint64_t)n, &count, &pre_ms, &run_ms);
+        smartgpu_text_free(text);
+        if (rc != SMARTGPU_OK || count > 0x7fffffffull) { fprintf(stderr, "%s\n", smartgpu_last_error()); return 1; }
+        *pre_time = pre_ms;   /* END_PREPROCESSING, main.h:30 */
+        *run_time = run_ms;   /* END_SEARCHING,     main.h:31 */
+        *result = (int)count; /* main.h:120 */
+        return 0;
+    }
+    if (argc < 5) {
+        printf("error in input parameter\nfour parameters needed in standard mode\n");
+        return 1;
+    }
+    int occ = -1;
+    {
+        const unsigned char *p = (const unsigned char *)argv[1], *t = (const unsigned char *)argv[3];
+        const int m = atoi(argv[2]), n = atoi(argv[4]);
+        smartgpu_text *text = smartgpu_text_upload(t, (uint64_t)n, 0);
+        uint64_t count = 0;
+        if (text && smartgpu_search64(SMARTGPU_ALGO, p, (uint32_t)m, text, 0, (uint64_t)n, &count, NULL, NULL) == SMARTGPU_OK)
+            occ = (int)count;
+        smartgpu_text_free(text);
+    }
+    printf("found %d occurrences\n", occ);
+    return occ < 0;
+}

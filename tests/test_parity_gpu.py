@@ -86,6 +86,24 @@ def test_skip_loops_forced_for_short_patterns(oracle):
         engine.tune(0, 0)
 
 
+def test_alternate_serial_kernels(oracle):
+    """SO and KMP normally run on the runs-through-LDS kernels; the LDS-tile variants
+    (kept for A/B measurements) must give the same counts."""
+    from smart_amd import engine
+    engine.tune(6, 1)
+    engine.tune(3, 1)
+    try:
+        for r in load_golden("fuzz_vectors.json")["rows"][::2]:
+            P, T = fuzz_case(oracle, r)
+            text = Text.upload(T)
+            got = gpu_counts(P, text, algos=("so", "kmp"))
+            text.free()
+            assert got["so"] == r["count"] and got["kmp"] == r["count"], (r, got)
+    finally:
+        engine.tune(6, 0)
+        engine.tune(3, 0)
+
+
 def test_survey_vectors(oracle):
     g = load_golden("survey_vectors.json")
     texts = {}

@@ -1,0 +1,65 @@
+"""Process-level drop-in check: the REFERENCE's own harness binaries (src/test.c and
+src/smart.c compiled as they are into oracle/_ref/bin, where /root/reference exists)
+drive this project's plugin executables through SMART's unchanged shm/exec protocol
+(src/smart.c:140-146, src/algos/include/main.h:42-122)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+REFBIN = os.path.join(ROOT, "oracle", "_ref", "bin")
+PLUGINS = os.path.join(ROOT, "smart_amd", "bin", "plugins")
+ALGOS = ["hor", "bm", "kmp", "so", "bndm", "epsm"]
+
+
+@pytest.fixture(scope="module")
+def smart_tree(tmp_path_factory, oracle):
+    if not os.path.exists(os.path.join(REFBIN, "test")):
+        pytest.skip("oracle/_ref/bin not built (no /root/reference on the build host)")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "smart_amd", "host")])
+    # some kernels refuse SysV shm; then this check cannot run here
+    probe = subprocess.run(["ipcs", "-m"], capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("SysV shared memory not available")
+    d = tmp_path_factory.mktemp("smart_tree")
+    # the layout the reference hard-codes (SURVEY.md §2 "Layout drift")
+    os.makedirs(d / "source" / "bin")
+    for a in ALGOS:
+        shutil.copy(os.path.join(PLUGINS, a), d / "source" / "bin" / a)
+    # executables copied out of the tree: point their rpath-relative library lookup at the real one
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "smart_amd", "csrc") + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    with open(d / "source" / "algorithms.h", "w") as f:
+        for a in sorted(ALGOS):
+            f.write("#1 #%s \n" % a)
+    os.makedirs(d / "data" / "rand128")
+    with open(d / "data" / "rand128" / "index.txt", "w") as f:
+        f.write("random text over 128 chars\n#rand128.txt#\n")
+    oracle.textgen(128, 2 * 1048576).tofile(str(d / "data" / "rand128" / "rand128.txt"))
+    os.makedirs(d / "results")
+    for tool in ("test", "smart"):
+        shutil.copy(os.path.join(REFBIN, tool), d / tool)
+    return d, env
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_reference_test_binary_passes(smart_tree, algo):
+    d, env = smart_tree
+    r = subprocess.run(["./test", algo], cwd=str(d), env=env, capture_output=True, text=True, timeout=600)
+    assert "Well done! Test passed successfully" in r.stdout, r.stdout + r.stderr
+
+
+def test_reference_smart_binary_reports_ok(smart_tree):
+    d, env = smart_tree
+    r = subprocess.run(["./smart", "-text", "rand128", "-plen", "32", "32", "-pset", "3", "-occ", "-pre"],
+                       cwd=str(d), env=env, capture_output=True, text=True, timeout=900)
+    out = r.stdout
+    assert "Testing 6 algorithms" in out, out + r.stderr
+    for a in ALGOS:
+        line = [ln for ln in out.splitlines() if re.search(r"\] %s \." % a.upper(), ln)]
+        assert line and "[OK]" in line[0] and re.search(r"occ [1-9]", line[0]), (a, out)
