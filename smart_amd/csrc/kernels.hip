@@ -34,6 +34,20 @@ namespace sg {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
 
+// 16-byte load of text that is read once: non-temporal (global_load_dwordx4 ... nt).
+// Measured with tools/probe/read_bw.hip on MI355X: a coalesced streaming read reaches
+// 7.0-7.1 TB/s with nt loads against 6.2-6.3 TB/s with the default cache policy.
+__device__ __forceinline__ uint4 ld_stream16(const uint8_t* p)
+{
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 v;
+    v.x = __builtin_nontemporal_load(&q->x);
+    v.y = __builtin_nontemporal_load(&q->y);
+    v.z = __builtin_nontemporal_load(&q->z);
+    v.w = __builtin_nontemporal_load(&q->w);
+    return v;
+}
+
 // Stage nbytes (multiple of 16) from 16-byte-aligned global memory to
 // 16-byte-aligned LDS, 16 B per lane per step (coalesced 1 KiB per wave-load).
 template <int THREADS>
@@ -41,7 +55,7 @@ __device__ __forceinline__ void stage_bytes(uint8_t* __restrict__ lds,
                                             const uint8_t* __restrict__ src, uint32_t nbytes)
 {
     for (uint32_t o = threadIdx.x * 16u; o < nbytes; o += THREADS * 16u)
-        *reinterpret_cast<uint4*>(lds + o) = *reinterpret_cast<const uint4*>(src + o);
+        *reinterpret_cast<uint4*>(lds + o) = ld_stream16(src + o);
 }
 
 // Fixed-size variant: TB bytes with all loads issued before the LDS stores.
@@ -54,7 +68,7 @@ __device__ __forceinline__ void stage_tile(uint8_t* __restrict__ lds,
     uint4 v[N];
 #pragma unroll
     for (int k = 0; k < N; ++k)
-        v[k] = *reinterpret_cast<const uint4*>(src + (k * THREADS + threadIdx.x) * 16);
+        v[k] = ld_stream16(src + (k * THREADS + threadIdx.x) * 16);
 #pragma unroll
     for (int k = 0; k < N; ++k)
         *reinterpret_cast<uint4*>(lds + (k * THREADS + threadIdx.x) * 16) = v[k];
@@ -156,11 +170,11 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
     const bool halo_lane = threadIdx.x * 16u < H16;
     auto issue = [&](uint64_t tile0) {
         const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
-        p0 = *reinterpret_cast<const uint4*>(src);
-        p1 = *reinterpret_cast<const uint4*>(src + THREADS * 16);
-        p2 = *reinterpret_cast<const uint4*>(src + THREADS * 32);
-        p3 = *reinterpret_cast<const uint4*>(src + THREADS * 48);
-        if (halo_lane) ph = *reinterpret_cast<const uint4*>(src - H16);
+        p0 = ld_stream16(src);
+        p1 = ld_stream16(src + THREADS * 16);
+        p2 = ld_stream16(src + THREADS * 32);
+        p3 = ld_stream16(src + THREADS * 48);
+        if (halo_lane) ph = ld_stream16(src - H16);
     };
     uint64_t t = tile_first + blockIdx.x;
     issue(t * TB);
@@ -275,11 +289,11 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
     uint4 v0, v1, v2, v3, hv;
     auto issue = [&](uint64_t tile0) {
         const uint8_t* src = a.text + tile0 + wave * 4096u + lane * 16u;
-        v0 = *reinterpret_cast<const uint4*>(src);
-        v1 = *reinterpret_cast<const uint4*>(src + 1024);
-        v2 = *reinterpret_cast<const uint4*>(src + 2048);
-        v3 = *reinterpret_cast<const uint4*>(src + 3072);
-        if (tid * 16u < H16) hv = *reinterpret_cast<const uint4*>(a.text + tile0 - H16 + tid * 16u);
+        v0 = ld_stream16(src);
+        v1 = ld_stream16(src + 1024);
+        v2 = ld_stream16(src + 2048);
+        v3 = ld_stream16(src + 3072);
+        if (tid * 16u < H16) hv = ld_stream16(a.text + tile0 - H16 + tid * 16u);
     };
     uint64_t t = tile_first + blockIdx.x;
     issue(t * TB);
@@ -363,11 +377,11 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
     const bool halo_lane = threadIdx.x * 16u < H16;
     auto issue = [&](uint64_t tile0) {
         const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
-        p0 = *reinterpret_cast<const uint4*>(src);
-        p1 = *reinterpret_cast<const uint4*>(src + THREADS * 16);
-        p2 = *reinterpret_cast<const uint4*>(src + THREADS * 32);
-        p3 = *reinterpret_cast<const uint4*>(src + THREADS * 48);
-        if (halo_lane) ph = *reinterpret_cast<const uint4*>(src - H16);
+        p0 = ld_stream16(src);
+        p1 = ld_stream16(src + THREADS * 16);
+        p2 = ld_stream16(src + THREADS * 32);
+        p3 = ld_stream16(src + THREADS * 48);
+        if (halo_lane) ph = ld_stream16(src - H16);
     };
     const uint64_t t_end = tile_first + ntiles;
     uint64_t t = tile_first + blockIdx.x;
@@ -464,11 +478,11 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
     const bool halo_lane = threadIdx.x * 16u < H16;
     auto issue = [&](uint64_t tile0) {
         const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
-        p0 = *reinterpret_cast<const uint4*>(src);
-        p1 = *reinterpret_cast<const uint4*>(src + THREADS * 16);
-        p2 = *reinterpret_cast<const uint4*>(src + THREADS * 32);
-        p3 = *reinterpret_cast<const uint4*>(src + THREADS * 48);
-        if (halo_lane) ph = *reinterpret_cast<const uint4*>(src - H16);
+        p0 = ld_stream16(src);
+        p1 = ld_stream16(src + THREADS * 16);
+        p2 = ld_stream16(src + THREADS * 32);
+        p3 = ld_stream16(src + THREADS * 48);
+        if (halo_lane) ph = ld_stream16(src - H16);
     };
     const uint64_t t_end = tile_first + ntiles;
     uint64_t t = tile_first + blockIdx.x;
@@ -566,12 +580,12 @@ __global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a, uint64_t tile_fir
     const bool halo_lane = threadIdx.x < 2;
     auto issue = [&](uint64_t tile0) {
         const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
-        p0 = *reinterpret_cast<const uint4*>(src);
-        p1 = *reinterpret_cast<const uint4*>(src + THREADS * 16);
-        p2 = *reinterpret_cast<const uint4*>(src + THREADS * 32);
-        p3 = *reinterpret_cast<const uint4*>(src + THREADS * 48);
-        p4 = *reinterpret_cast<const uint4*>(src + THREADS * 64);
-        if (halo_lane) ph = *reinterpret_cast<const uint4*>(src + TB);
+        p0 = ld_stream16(src);
+        p1 = ld_stream16(src + THREADS * 16);
+        p2 = ld_stream16(src + THREADS * 32);
+        p3 = ld_stream16(src + THREADS * 48);
+        p4 = ld_stream16(src + THREADS * 64);
+        if (halo_lane) ph = ld_stream16(src + TB);
     };
     uint64_t t = tile_first + blockIdx.x;
     issue(t * TB);
@@ -1027,17 +1041,17 @@ struct EpsmFp { uint32_t f0, f1, f2, f3, k0, k1, k2, k3, nd, m; };
 template <int MODE>
 static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const EpsmFp& fp,
                                                     const uint4& A, const uint4& Bv, uint64_t p0,
-                                                    uint32_t& pending)
+                                                    uint32_t& pending, bool overlap_lane)
 {
     const uint32_t d[8] = {A.x, A.y, A.z, A.w, Bv.x, Bv.y, Bv.z, Bv.w};
     // offsets k with p0+k inside [s_begin, s_end)
-    uint32_t cand = 0xFFFFu;
+    uint32_t cand = overlap_lane ? 0u : 0xFFFFu;
     if (p0 < a.s_begin || p0 + 16 > a.s_end) {
         const uint64_t lo64 = a.s_begin > p0 ? a.s_begin - p0 : 0;
         const uint64_t hi64 = a.s_end > p0 ? a.s_end - p0 : 0;
         const uint32_t lo = lo64 > 16 ? 16u : (uint32_t)lo64;
         const uint32_t hi = hi64 > 16 ? 16u : (uint32_t)hi64;
-        cand = hi > lo ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+        cand = (hi > lo && !overlap_lane) ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
     }
     constexpr bool VERIFY = MODE == 2;
 #define SG_EQ(x, kk, ff) (MODE != 0 ? (SG_W(x) == (ff)) : ((SG_W(x) & (kk)) == (ff)))
@@ -1096,10 +1110,14 @@ static __device__ __attribute__((noinline)) uint32_t epsm_verify(const uint8_t* 
 
 // ALGO only tags the instantiation (rocprofv3 shows packed_scan<256, 4, 5, ..> for
 // EPSM and packed_scan<256, 4, 0, ..> for Horspool's short-pattern regime).
-template <int THREADS, int ROWS, int ALGO, int MODE>
+template <int THREADS, int ROWS, int ALGO, int MODE, int POLICY>
 __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_first,
                                                        uint64_t nrows)
 {
+    // POLICY 0: A non-temporal, B cached (default); 1: both cached; 3: one nt load + shuffle.
+    // (Both loads nt measured 62-67 %: the second load must find the line still cached.  A
+    // ballot/SGPR formulation of the first-dword test measured 59-73 %: scalar-unit bound.)
+    constexpr bool NTA = POLICY != 1, NTB = false;
     const uint32_t* fpw = reinterpret_cast<const uint32_t*>(a.blob + a.fp_off);
     EpsmFp fp;
     fp.f0 = fpw[0]; fp.f1 = fpw[1]; fp.f2 = fpw[2]; fp.f3 = fpw[3];
@@ -1108,23 +1126,44 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_
     fp.nd = (a.m >= 13) ? 4 : (a.m + 3) / 4;  // fingerprint dwords
 
     uint32_t hits = 0;
-    // a "row" is THREADS*16 consecutive absolute text offsets; a workgroup takes
-    // ROWS consecutive rows per step
+    // POLICY 3: a wave-row is 63*16 = 1008 start positions; lane i loads the 16 bytes at
+    // row + 16*i ONCE (non-temporal) and takes the next 16 bytes from lane i+1 by a
+    // cross-lane shuffle; lane 63 only supplies the overlap into the next wave-row.
+    // Other policies: a row is THREADS*16 offsets and every lane loads 32 bytes.
+    constexpr bool SHUF = POLICY == 3;
+    constexpr uint32_t ROW_BYTES = SHUF ? (THREADS / 64) * 1008u : THREADS * 16u;
+    const uint32_t in_row = SHUF ? (threadIdx.x >> 6) * 1008u + (threadIdx.x & 63u) * 16u : threadIdx.x * 16u;
+    // a workgroup takes ROWS consecutive rows per step
     for (uint64_t g = (uint64_t)blockIdx.x * ROWS; g < nrows; g += (uint64_t)gridDim.x * ROWS) {
         uint4 A[ROWS], B[ROWS];
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             const uint64_t r = g + j < nrows ? g + j : nrows - 1;  // clamp, ignored below
-            const uint8_t* src = a.text + ((row_first + r) * THREADS + threadIdx.x) * 16;
-            A[j] = *reinterpret_cast<const uint4*>(src);
-            B[j] = *reinterpret_cast<const uint4*>(src + 16);
+            const uint8_t* src = a.text + (row_first + r) * ROW_BYTES + in_row;
+            if (SHUF) {
+                A[j] = ld_stream16(src);
+            } else {
+                // A is this lane's own 16 bytes; B re-reads the next lane's 16 bytes
+                A[j] = NTA ? ld_stream16(src) : *reinterpret_cast<const uint4*>(src);
+                B[j] = NTB ? ld_stream16(src + 16) : *reinterpret_cast<const uint4*>(src + 16);
+            }
+        }
+        if (SHUF) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                B[j].x = __shfl_down(A[j].x, 1, 64);
+                B[j].y = __shfl_down(A[j].y, 1, 64);
+                B[j].z = __shfl_down(A[j].z, 1, 64);
+                B[j].w = __shfl_down(A[j].w, 1, 64);
+            }
         }
         uint32_t pend[ROWS];
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             pend[j] = 0;
             if (g + j < nrows)
-                hits += epsm_row<MODE>(a, fp, A[j], B[j], ((row_first + g + j) * THREADS + threadIdx.x) * 16, pend[j]);
+                hits += epsm_row<MODE>(a, fp, A[j], B[j], (row_first + g + j) * ROW_BYTES + in_row, pend[j],
+                                       SHUF && (threadIdx.x & 63u) == 63u);
         }
         if (MODE == 2) {
             uint32_t any_pend = 0;
@@ -1138,7 +1177,7 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_
                     for (int q = 1; q < ROWS; ++q)
                         if (j == q) c = pend[q];
                     if (__any(c != 0))
-                        hits += epsm_verify(a.text, a.blob, a.m, c, ((row_first + g + j) * THREADS + threadIdx.x) * 16);
+                        hits += epsm_verify(a.text, a.blob, a.m, c, (row_first + g + j) * ROW_BYTES + in_row);
                 }
             }
         }
@@ -1212,7 +1251,8 @@ __global__ __launch_bounds__(256) void probe_read(const uint8_t* text, uint64_t 
     for (uint64_t i = (uint64_t)blockIdx.x * 256 * 8 + threadIdx.x; i < n16; i += stride) {
         uint4 v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = i + k * 256 < n16 ? p[i + k * 256] : uint4{0, 0, 0, 0};
+        for (int k = 0; k < 8; ++k)
+            v[k] = i + k * 256 < n16 ? ld_stream16(reinterpret_cast<const uint8_t*>(p + i + k * 256)) : uint4{0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 8; ++k) { acc.x ^= v[k].x; acc.y ^= v[k].y; acc.z ^= v[k].z; acc.w ^= v[k].w; }
     }
@@ -1322,25 +1362,26 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
 template <int ALGO>
 static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stream)
 {
-    const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kEpsmT * 16);
+    const bool shuf = g_tune[7] == 3;
+    const TileRange tr = tiles_for(a.s_begin, a.s_end, shuf ? (uint64_t)(kEpsmT / 64) * 1008 : (uint64_t)kEpsmT * 16);
     if (tr.count == 0) return hipSuccess;
-    const int rows = g_tune[2] ? g_tune[2] : 4;  // rows in flight per workgroup step
+    const int rows = 4;  // rows in flight per workgroup step (1 and 2 measured slower, profiles/r01)
     uint64_t grid = ((uint64_t)tr.count + rows - 1) / rows;
     const uint64_t cap = (uint64_t)num_cus * 8;
     if (grid > cap) grid = cap;
-#define SG_PACKED(R_, M_)                                                                          \
-    hipLaunchKernelGGL((packed_scan<kEpsmT, R_, ALGO, M_>), dim3((uint32_t)grid), dim3(kEpsmT), 0,   \
+#define SG_PACKED(M_, P_)                                                                           \
+    hipLaunchKernelGGL((packed_scan<kEpsmT, 4, ALGO, M_, P_>), dim3((uint32_t)grid), dim3(kEpsmT), 0,   \
                        stream, a, tr.first, (uint64_t)tr.count)
-#define SG_PACKED_ROWS(M_)                                                   \
+#define SG_PACKED_POLICY(M_)                                                 \
     do {                                                                     \
-        if (rows == 1) SG_PACKED(1, M_);                                     \
-        else if (rows == 2) SG_PACKED(2, M_);                                \
-        else SG_PACKED(4, M_);                                               \
+        if (g_tune[7] == 1) SG_PACKED(M_, 1);                                \
+        else if (g_tune[7] == 3) SG_PACKED(M_, 3);                           \
+        else SG_PACKED(M_, 0);                                               \
     } while (0)
-    if (a.m > 16) SG_PACKED_ROWS(2);
-    else if (a.m % 4 == 0) SG_PACKED_ROWS(1);
-    else SG_PACKED_ROWS(0);
-#undef SG_PACKED_ROWS
+    if (a.m > 16) SG_PACKED_POLICY(2);
+    else if (a.m % 4 == 0) SG_PACKED_POLICY(1);
+    else SG_PACKED_POLICY(0);
+#undef SG_PACKED_POLICY
 #undef SG_PACKED
     return hipGetLastError();
 }

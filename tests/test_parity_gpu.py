@@ -86,6 +86,30 @@ def test_skip_loops_forced_for_short_patterns(oracle):
         engine.tune(0, 0)
 
 
+@pytest.mark.parametrize("policy", [1, 3])
+def test_packed_load_policies(oracle, policy):
+    """The packed matcher's alternative data paths (both loads cached / one
+    non-temporal load + cross-lane shuffle) give the same counts."""
+    from smart_amd import engine
+    engine.tune(7, policy)
+    try:
+        for r in load_golden("fuzz_vectors.json")["rows"][::2]:
+            P, T = fuzz_case(oracle, r)
+            text = Text.upload(T)
+            got = gpu_counts(P, text, algos=("epsm", "hor"))
+            text.free()
+            assert got["epsm"] == r["count"] and got["hor"] == r["count"], (policy, r, got)
+        T = oracle.gen_text(5, 2, 0, 3_000_000)
+        text = Text.upload(T)
+        for m in (1, 3, 8, 16, 17, 100):
+            P = T[999:999 + m]
+            want = oracle.search("epsm", P, T)
+            assert smart_amd.search("epsm", P, text)[0] == want, (policy, m)
+            assert smart_amd.search("epsm", P, text, off=1234567, n=1000001)[0] == oracle.search("epsm", P, T[1234567:2234568]), (policy, m)
+    finally:
+        engine.tune(7, 0)
+
+
 def test_alternate_serial_kernels(oracle):
     """SO and KMP normally run on the runs-through-LDS kernels; the LDS-tile variants
     (kept for A/B measurements) must give the same counts."""
