@@ -174,7 +174,7 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
     auto tiny_shifts = [&](const std::vector<int32_t>& bc) {
         uint64_t sum = 0;
         for (uint32_t i = 0; i < m; ++i) sum += static_cast<uint64_t>(bc[P[i]]);
-        return m > 16 && sum < 6ull * m;
+        return m > 7 && sum < 6ull * m;
     };
     *halo = std::min<uint32_t>(m - 1, sg::kHaloMax);
     switch (algo) {

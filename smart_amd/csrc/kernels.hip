@@ -1298,7 +1298,12 @@ hipError_t launch_tiled(K kernel, const ScanArgs& a, TileRange tr, int threads, 
 }  // namespace
 
 int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-constexpr uint32_t kPackedMaxM = 16;  // skip algorithms use the packed matcher up to this m
+// skip algorithms use the packed matcher up to this m (crossovers measured on 1 GiB rand128
+// with non-temporal tile loads, profiles/r01): HOR 7, BM 13, BNDM 11
+static constexpr uint32_t packed_max_m(int algo)
+{
+    return algo == SMARTGPU_HOR ? 7u : algo == SMARTGPU_BM ? 13u : algo == SMARTGPU_BNDM ? 11u : 0u;
+}
 
 // tile shapes (threads, bytes per lane)
 constexpr int kHorT = 256, kHorL = 64;
@@ -1317,10 +1322,10 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
             const int r = pk ? 3 : hor_regime(m);
             return r == 3 ? "packed_scan" : r == 2 ? "hor_scan_bp" : "hor_scan";
         }
-        case SMARTGPU_BM: return (pk || (m <= kPackedMaxM && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
+        case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : "kmp_runs";
         case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : "so_runs";
-        case SMARTGPU_BNDM: return (m <= kPackedMaxM && g_tune[0] != 1) ? "packed_scan" : "bndm_scan";
+        case SMARTGPU_BNDM: return (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1) ? "packed_scan" : "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
     }
     return "?";
@@ -1386,12 +1391,12 @@ static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stre
     return hipGetLastError();
 }
 
-// Regimes of the skip algorithms (HOR, BM, BNDM).  For m <= 16 the window is at most
-// four dwords and a skip loop degenerates (a lane advances ~m bytes per two dependent
+// Regimes of the skip algorithms (HOR, BM, BNDM).  For short patterns the window is a
+// few dwords and a skip loop degenerates (a lane advances ~m bytes per two dependent
 // LDS reads); the packed matcher tests every alignment at HBM speed instead — the
 // "hybrid" SURVEY.md §7 describes; counts are identical.  Measured on 1 GiB rand128
-// (profiles/r01): HOR m=4: flat tile 45 %, bank-private 55 %, packed 74 % of 8 TB/s;
-// BM/BNDM m=9..16: skip loop 44-58 %, packed 72 %.
+// (profiles/r01): HOR m=4: flat tile 45 %, bank-private 55 %, packed 74 % of 8 TB/s.
+// Thresholds per algorithm: packed_max_m().
 
 static int hor_regime(uint32_t m)
 {
@@ -1399,7 +1404,7 @@ static int hor_regime(uint32_t m)
     if (v == 3) return 3;
     if (v == 2) return m <= kHaloMax + 1 ? 2 : 1;  // the bank-private kernel keeps whole windows in LDS
     if (v == 1) return 1;
-    return m <= kPackedMaxM ? 3 : 1;  // bank-private kernel: only on request
+    return m <= packed_max_m(SMARTGPU_HOR) ? 3 : 1;  // bank-private kernel: only on request
 }
 
 hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream)
@@ -1426,7 +1431,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             return launch_tiled(hor_scan<kHorT, kHorL, false>, a, tr, kHorT, lds, 8, num_cus, stream);
         }
         case SMARTGPU_BM: {
-            if ((m <= kPackedMaxM && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
+            if ((m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
                 ScanArgs b = a;
                 b.fp_off = kTableOff + ((512 + 2 * (m + 1) + 3) & ~3u);  // after bc, gs, safe shift
                 return launch_packed<SMARTGPU_BM>(b, num_cus, stream);
@@ -1438,7 +1443,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             return launch_tiled(bm_scan<kBmT, kBmL, false>, a, tr, kBmT, lds, 6, num_cus, stream);
         }
         case SMARTGPU_BNDM: {
-            if (m <= kPackedMaxM && g_tune[0] != 1) {
+            if (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1) {
                 ScanArgs b = a;
                 b.fp_off = kTableOff + 1024;  // after B[256]
                 return launch_packed<SMARTGPU_BNDM>(b, num_cus, stream);
