@@ -1439,8 +1439,9 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             const uint32_t H = a.halo;
             const size_t lds = 512 + r16(2 * (m + 1)) + r16(H + 1) + r16(H) + (size_t)kBmT * kBmL;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmT * kBmL);
-            if (m - 1 > H) return launch_tiled(bm_scan<kBmT, kBmL, true>, a, tr, kBmT, lds, 6, num_cus, stream);
-            return launch_tiled(bm_scan<kBmT, kBmL, false>, a, tr, kBmT, lds, 6, num_cus, stream);
+            const int wgs = g_tune[4] ? g_tune[4] : (lds <= 20 * 1024 ? 8 : 6);  // workgroups per CU by LDS footprint
+            if (m - 1 > H) return launch_tiled(bm_scan<kBmT, kBmL, true>, a, tr, kBmT, lds, wgs, num_cus, stream);
+            return launch_tiled(bm_scan<kBmT, kBmL, false>, a, tr, kBmT, lds, wgs, num_cus, stream);
         }
         case SMARTGPU_BNDM: {
             if (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1) {
