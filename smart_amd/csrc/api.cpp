@@ -167,14 +167,17 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         }
         append(fp, sizeof fp);
     };
-    // Mean bad-character shift if the text's symbols are distributed like the pattern's
-    // own.  Below ~6 bytes (binary / DNA-like alphabets) a skip loop verifies almost every
-    // window and lanes diverge; the packed matcher is the better regime there (measured
-    // on rand2/rand4).  The count does not depend on the choice.
+    // Mean bad-character shift E if the text's symbols are distributed like the pattern's
+    // own.  A pattern over a large alphabet has E ~ m/2; E well below that (and below ~12
+    // bytes) means repeated symbols — binary/DNA-like alphabets, natural language — where a
+    // skip loop verifies windows all the time and lanes diverge, and the packed matcher is
+    // the better regime (measured on rand2/rand4/English).  The count does
+    // not depend on the choice.
     auto tiny_shifts = [&](const std::vector<int32_t>& bc) {
         uint64_t sum = 0;
         for (uint32_t i = 0; i < m; ++i) sum += static_cast<uint64_t>(bc[P[i]]);
-        return m > 7 && sum < 6ull * m;
+        const double e = static_cast<double>(sum) / m;
+        return m > 7 && e < std::min(0.4 * m, 12.0);
     };
     *halo = std::min<uint32_t>(m - 1, sg::kHaloMax);
     switch (algo) {
@@ -231,7 +234,8 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         case SMARTGPU_BNDM: {
             const std::vector<uint32_t> B = sg::bndm_masks(P, m);
             append(B.data(), 1024);
-            append_fingerprint();  // m <= 8 regime
+            append_fingerprint();  // packed regime
+            *prefer_packed = tiny_shifts(sg::bad_char(P, m));
             break;
         }
         case SMARTGPU_EPSM:

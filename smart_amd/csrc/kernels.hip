@@ -1325,7 +1325,7 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
         case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : "kmp_runs";
         case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : "so_runs";
-        case SMARTGPU_BNDM: return (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1) ? "packed_scan" : "bndm_scan";
+        case SMARTGPU_BNDM: return (pk || (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1)) ? "packed_scan" : "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
     }
     return "?";
@@ -1444,7 +1444,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             return launch_tiled(bm_scan<kBmT, kBmL, false>, a, tr, kBmT, lds, wgs, num_cus, stream);
         }
         case SMARTGPU_BNDM: {
-            if (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1) {
+            if ((m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
                 ScanArgs b = a;
                 b.fp_off = kTableOff + 1024;  // after B[256]
                 return launch_packed<SMARTGPU_BNDM>(b, num_cus, stream);
