@@ -104,6 +104,7 @@ struct smartgpu_plan {
     uint32_t m = 0;
     uint32_t halo = 0;
     uint32_t prefer_packed = 0;  // see build_blob
+    uint32_t kmp_k1 = 0;         // see build_blob
     uint8_t* blob = nullptr;               // device: pattern + tables
     unsigned long long* results = nullptr; // device: kResultSlots counters (library-owned)
     unsigned long long* ext_results = nullptr; // caller-owned device buffer, if set
@@ -147,9 +148,10 @@ smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
 
 // Build the device blob (pattern + tables) for (algo, P, m) in a host vector.
 std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t* halo,
-                                uint32_t* prefer_packed)
+                                uint32_t* prefer_packed, uint32_t* kmp_k1)
 {
     *prefer_packed = 0;
+    *kmp_k1 = 0;
     std::vector<uint8_t> blob(sg::kPatternBytes, 0);
     std::memcpy(blob.data(), P, m);
     auto append = [&blob](const void* p, size_t bytes) {
@@ -223,6 +225,14 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
                 blob.resize((blob.size() + 15) & ~size_t(15), 0);
                 const std::vector<uint8_t> dfa = sg::kmp_dfa(P, m);
                 append(dfa.data(), dfa.size());
+            } else if (m <= sg::kKmpDfaCompMaxM) {  // table over the pattern's own alphabet
+                uint32_t k1 = 0;
+                const std::vector<uint8_t> dfa = sg::kmp_dfa_compressed(P, m, &k1);
+                if (dfa.size() - 256 <= sg::kKmpDfaCompMaxBytes) {
+                    blob.resize((blob.size() + 15) & ~size_t(15), 0);
+                    append(dfa.data(), dfa.size());
+                    *kmp_k1 = k1;
+                }
             }
             break;
         }
@@ -267,6 +277,7 @@ sg::ScanArgs make_args(const smartgpu_plan* p, const smartgpu_text* text, uint64
     a.halo = p->halo;
     a.fp_off = 0;
     a.prefer_packed = p->prefer_packed;
+    a.kmp_k1 = p->kmp_k1;
     a.blob = p->blob;
     a.count = p->slot_ptr(slot);
     return a;
@@ -404,7 +415,7 @@ smartgpu_plan* smartgpu_plan_create(int algo, const uint8_t* P, uint32_t m, int 
     p->device = device;
     p->algo = algo;
     p->m = m;
-    const std::vector<uint8_t> blob = build_blob(algo, P, m, &p->halo, &p->prefer_packed);
+    const std::vector<uint8_t> blob = build_blob(algo, P, m, &p->halo, &p->prefer_packed, &p->kmp_k1);
     bool ok = hipMalloc(reinterpret_cast<void**>(&p->blob), blob.size()) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&p->results), sizeof(unsigned long long) * sg::kResultSlots) == hipSuccess;
     if (ok) {

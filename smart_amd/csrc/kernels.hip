@@ -813,7 +813,35 @@ __device__ __forceinline__ void kmp_dfa_chunk(const uint4& v, uint32_t j_base, u
     }
 }
 
-template <bool DFA>
+// Compressed table: the 16 column lookups colmap[c] do not depend on the state and are
+// issued together; the state chain then costs one dependent lookup per byte as above.
+template <bool CHECK>
+__device__ __forceinline__ void kmp_dfac_chunk(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
+                                               uint32_t& st, uint32_t& hits, uint32_t m, uint32_t k1,
+                                               const uint8_t* __restrict__ colmap,
+                                               const uint8_t* __restrict__ table)
+{
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+    uint32_t col[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) col[q] = colmap[(d[q >> 2] >> (8 * (q & 3))) & 0xFFu];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t nx = table[st * k1 + col[q]];
+        if (CHECK) {
+            const uint32_t j = j_base + q;
+            const bool live = j >= j0 && j < jend;
+            st = live ? nx : st;
+            hits += live && nx == m;
+        } else {
+            st = nx;
+            hits += nx == m;
+        }
+    }
+}
+
+// DFA: 0 failure links, 1 full 256-column table (m <= 95), 2 table over the pattern's alphabet
+template <int DFA>
 __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
                                                 uint32_t dfa_off)
 {
@@ -821,13 +849,15 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
     const uint32_t m = a.m;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // LDS: [table][4 wave slabs]
-    const uint32_t table_bytes = DFA ? round16((m + 1) * 256) : round16(4 * m);
+    const uint32_t k1 = a.kmp_k1;
+    const uint32_t table_bytes = DFA == 1 ? round16((m + 1) * 256)
+                               : DFA == 2 ? round16(256 + (m + 1) * k1) : round16(4 * m);
     uint8_t* slab = smem + table_bytes + wave * kRunSlab;
     const int16_t* gnext = reinterpret_cast<const int16_t*>(a.blob + kTableOff);
-    if (DFA) {
+    if (DFA != 0) {
         const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
         uint4* t = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = threadIdx.x; i < (m + 1) * 16; i += 256) t[i] = g[i];
+        for (uint32_t i = threadIdx.x; i < table_bytes / 16; i += 256) t[i] = g[i];
     } else {
         uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
         for (uint32_t i = threadIdx.x; i < m; i += 256)
@@ -892,9 +922,12 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
                 const uint4 v = *reinterpret_cast<const uint4*>(mine + 16 * q);
                 const uint32_t j = jb + 16u * q;
                 const bool full = j >= j0 && j + 16 <= jend;
-                if (DFA) {
+                if (DFA == 1) {
                     if (full) kmp_dfa_chunk<false>(v, j, j0, jend, st, hits, m, dfa);
                     else if (j < jend && j + 16 > j0) kmp_dfa_chunk<true>(v, j, j0, jend, st, hits, m, dfa);
+                } else if (DFA == 2) {
+                    if (full) kmp_dfac_chunk<false>(v, j, j0, jend, st, hits, m, k1, dfa, dfa + 256);
+                    else if (j < jend && j + 16 > j0) kmp_dfac_chunk<true>(v, j, j0, jend, st, hits, m, k1, dfa, dfa + 256);
                 } else {
                     if (full) kmp_chunk<false>(v, j, j0, jend, sti, hits, (int)m, p0, next_m, tab);
                     else if (j < jend && j + 16 > j0) kmp_chunk<true>(v, j, j0, jend, sti, hits, (int)m, p0, next_m, tab);
@@ -1346,18 +1379,21 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     L = (L + 63) & ~63ull;
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
-    const bool dfa = m <= kKmpDfaMaxM;
-    const size_t table = dfa ? r16((m + 1) * 256) : r16(4 * m);
+    const int dfa = m <= kKmpDfaMaxM ? 1 : a.kmp_k1 ? 2 : 0;
+    const size_t table = dfa == 1 ? r16((m + 1) * 256) : dfa == 2 ? r16(256 + (m + 1) * a.kmp_k1) : r16(4 * m);
     const size_t lds = table + 4 * (size_t)kRunSlab;
     uint64_t grid = ((uint64_t)tr.count + 255) / 256;
     const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 4);
     if (grid > cap) grid = cap;
     const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));
-    if (dfa)
-        hipLaunchKernelGGL(kmp_runs<true>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
+    if (dfa == 1)
+        hipLaunchKernelGGL(kmp_runs<1>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
+                           (uint64_t)tr.count, dfa_off);
+    else if (dfa == 2)
+        hipLaunchKernelGGL(kmp_runs<2>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
                            (uint64_t)tr.count, dfa_off);
     else
-        hipLaunchKernelGGL(kmp_runs<false>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
+        hipLaunchKernelGGL(kmp_runs<0>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
                            (uint64_t)tr.count, dfa_off);
     return hipGetLastError();
 }

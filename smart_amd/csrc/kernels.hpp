@@ -18,7 +18,9 @@ constexpr uint64_t kBackPad = 160 * 1024;       // >= largest tile + kXSize + 64
 constexpr uint32_t kHaloMax = 16;               // bytes a lane verifies by itself in LDS before it parks the window
 constexpr uint32_t kPatternBytes = 4224;        // pattern slot in the plan blob (>= kXSize, /16)
 constexpr int kResultSlots = 4096;
-constexpr uint32_t kKmpDfaMaxM = 95;            // KMP: (m+1)*256-byte transition table kept in LDS up to this m
+constexpr uint32_t kKmpDfaMaxM = 64;            // KMP: (m+1)*256-byte transition table kept in LDS up to this m
+constexpr uint32_t kKmpDfaCompMaxM = 255;       // ... and a table over the pattern's own alphabet up to this m,
+constexpr uint32_t kKmpDfaCompMaxBytes = 40960; //     if it fits this many bytes (u8 states)
 
 // What every scan kernel receives.
 struct ScanArgs {
@@ -28,6 +30,7 @@ struct ScanArgs {
     uint32_t halo;              // skip kernels: back-halo H = min(m-1, kHaloMax); serial: forward halo
     uint32_t fp_off;            // packed kernel: blob offset of the fingerprint (set by launch_scan)
     uint32_t prefer_packed;     // HOR/BM: the shift tables promise tiny shifts (small alphabet) -> packed regime
+    uint32_t kmp_k1;            // KMP: row stride of the compressed transition table, 0 if the blob has none
     const uint8_t* blob;        // device: [pattern kPatternBytes][tables ...]
     unsigned long long* count;  // device result slot (pre-zeroed)
 };

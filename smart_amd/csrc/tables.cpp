@@ -94,6 +94,21 @@ std::vector<uint8_t> kmp_dfa(const uint8_t* P, uint32_t m)
     return dfa;
 }
 
+std::vector<uint8_t> kmp_dfa_compressed(const uint8_t* P, uint32_t m, uint32_t* k1)
+{
+    const std::vector<uint8_t> full = kmp_dfa(P, m);
+    std::vector<uint8_t> out(256, 0);  // colmap
+    uint32_t ncol = 1;                 // column 0: bytes that do not occur in P
+    for (uint32_t i = 0; i < m; ++i)
+        if (out[P[i]] == 0) out[P[i]] = static_cast<uint8_t>(ncol++);  // at most 255 distinct for m <= 255
+    *k1 = ncol;
+    out.resize(256 + static_cast<size_t>(m + 1) * ncol, 0);
+    for (uint32_t s = 0; s <= m; ++s)
+        for (int c = 0; c < 256; ++c)
+            if (out[c] != 0) out[256 + static_cast<size_t>(s) * ncol + out[c]] = full[static_cast<size_t>(s) * 256 + c];
+    return out;
+}
+
 std::vector<uint32_t> shift_or_masks(const uint8_t* P, uint32_t m)
 {
     const uint32_t w = std::min<uint32_t>(m, 32);

@@ -28,6 +28,11 @@ std::vector<int32_t> kmp_next(const uint8_t* P, uint32_t m);
 // state m = "an occurrence ends here".  (m+1)*256 bytes.
 std::vector<uint8_t> kmp_dfa(const uint8_t* P, uint32_t m);
 
+// The same table over the pattern's own alphabet only: colmap[c] = column of byte c
+// (0 = "c does not occur in P": every state goes to 0), table[s*k1 + col], k1 columns.
+// Returns colmap (256 bytes) followed by the table; *k1 = row stride.
+std::vector<uint8_t> kmp_dfa_compressed(const uint8_t* P, uint32_t m, uint32_t* k1);
+
 // Shift-Or: S[c] has bit i clear iff P[i]==c, over the first w=min(m,32) bytes
 // (so.c:27-38,73-74).  The hit test "D < lim" (so.c:56) is "bit w-1 of D is 0".
 std::vector<uint32_t> shift_or_masks(const uint8_t* P, uint32_t m);
