@@ -153,7 +153,10 @@ int smartgpu_tune(int key, int value);
  *          1 BM good-suffix (m)           bm.c:36-66
  *          2 KMP failure function (m+1)   kmp.c:27-41
  *          3 Shift-Or masks (256)         so.c:27-38   (32-bit words, prefix of 32 for m>32)
- *          4 BNDM masks (256)             bndm.c:35-40 (same)                                  */
+ *          4 BNDM masks (256)             bndm.c:35-40 (same)
+ *          5 KMP transition table ((m+1)*256, m <= 255): the failure links of kmp.c:27-41
+ *            expanded into delta[state][byte]; state m = an occurrence ends here
+ *          6 the same over the pattern's own alphabet: k1, colmap[256], table[(m+1)*k1]    */
 int smartgpu_build_table(int which, const uint8_t *P, uint32_t m, int32_t *out, uint32_t cap);
 
 #ifdef __cplusplus

@@ -632,6 +632,20 @@ int smartgpu_build_table(int which, const uint8_t* P, uint32_t m, int32_t* out, 
         case 2: v = sg::kmp_next(P, m); break;
         case 3: { auto s = sg::shift_or_masks(P, m); v.assign(s.begin(), s.end()); break; }
         case 4: { auto b = sg::bndm_masks(P, m); v.assign(b.begin(), b.end()); break; }
+        case 5: {  // KMP transition table, (m+1)*256 entries (m <= 255)
+            if (m > 255) { set_error("the KMP transition table needs m <= 255"); return SMARTGPU_ERR_ARG; }
+            auto d = sg::kmp_dfa(P, m);
+            v.assign(d.begin(), d.end());
+            break;
+        }
+        case 6: {  // compressed form: [k1][colmap 256][table (m+1)*k1]
+            if (m > 255) { set_error("the KMP transition table needs m <= 255"); return SMARTGPU_ERR_ARG; }
+            uint32_t k1 = 0;
+            auto d = sg::kmp_dfa_compressed(P, m, &k1);
+            v.push_back(static_cast<int32_t>(k1));
+            v.insert(v.end(), d.begin(), d.end());
+            break;
+        }
         default: set_error("unknown table %d", which); return SMARTGPU_ERR_ARG;
     }
     if (v.size() > cap) { set_error("table needs %zu entries, cap %u", v.size(), cap); return SMARTGPU_ERR_ARG; }

@@ -71,3 +71,66 @@ def test_compute_fails_loudly_without_gpu():
     assert smart_amd.search_host("hor", T[:4], T) == -1
     with pytest.raises(smart_amd.SmartGpuError):
         smart_amd.Text.upload(T)
+
+
+def test_kmp_transition_tables_count_like_the_oracle(oracle):
+    """The KMP kernels run the failure function expanded into delta[state][byte]
+    (full and own-alphabet forms); walking those tables on the host must count
+    exactly what kmp.c counts."""
+    rng = np.random.default_rng(11)
+    for sigma, n, m in ((2, 3000, 5), (2, 3000, 40), (4, 4000, 17), (128, 5000, 3), (250, 5000, 200), (3, 2000, 255)):
+        T = oracle.gen_text(int(rng.integers(0, 2**40)), sigma, 0, n)
+        for P in (T[100:100 + m].copy(), np.resize(T[7:9], m)):
+            want = oracle.search("kmp", P, T)
+            dfa = smart_amd.build_table("kmp_dfa", P).reshape(m + 1, 256)
+            comp = smart_amd.build_table("kmp_dfa_compressed", P)
+            k1, colmap, table = int(comp[0]), comp[1:257], comp[257:].reshape(m + 1, -1)
+            assert table.shape[1] == k1
+            st = st2 = hits = hits2 = 0
+            for c in T.tolist():
+                st = int(dfa[st, c])
+                hits += st == m
+                st2 = int(table[st2, colmap[c]])
+                hits2 += st2 == m
+            assert hits == want and hits2 == want, (sigma, n, m, hits, hits2, want)
+
+
+def test_host_table_builders_under_sanitizers(tmp_path):
+    """tables.cpp (the host-side preprocessing the kernels depend on) built with
+    AddressSanitizer + UBSan on the CPU and driven over many patterns."""
+    import subprocess
+    src = os.path.join(ROOT, "smart_amd", "csrc", "tables.cpp")
+    drv = tmp_path / "drv.cpp"
+    drv.write_text(r"""
+#include "tables.hpp"
+#include <cstdio>
+#include <vector>
+int main() {
+    unsigned long long x = 88172645463325252ull, sink = 0;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    const unsigned ms[] = {1, 2, 3, 4, 7, 8, 31, 32, 33, 64, 65, 95, 96, 255, 256, 1000, 4200};
+    for (unsigned sigma : {1u, 2u, 4u, 128u, 256u})
+        for (unsigned m : ms)
+            for (int rep = 0; rep < 3; ++rep) {
+                std::vector<uint8_t> P(m);
+                for (auto& b : P) b = (uint8_t)(rnd() % sigma);
+                sink += sg::bad_char(P.data(), m)[P[0]];
+                sink += sg::good_suffix(P.data(), m)[0];
+                sink += sg::kmp_next(P.data(), m)[m];
+                sink += sg::shift_or_masks(P.data(), m)[P[0]];
+                sink += sg::bndm_masks(P.data(), m)[P[0]];
+                if (m <= 255) {
+                    uint32_t k1 = 0;
+                    sink += sg::kmp_dfa(P.data(), m)[m * 256u + P[0]];
+                    sink += sg::kmp_dfa_compressed(P.data(), m, &k1).size() + k1;
+                }
+            }
+    std::printf("ok %llu\n", sink);
+    return 0;
+}
+""")
+    exe = tmp_path / "drv"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(ROOT, "smart_amd", "csrc"), str(drv), src, "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
