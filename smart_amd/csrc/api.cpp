@@ -225,9 +225,10 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
                 blob.resize((blob.size() + 15) & ~size_t(15), 0);
                 const std::vector<uint8_t> dfa = sg::kmp_dfa(P, m);
                 append(dfa.data(), dfa.size());
-            } else if (m <= sg::kKmpDfaCompMaxM) {  // table over the pattern's own alphabet
+            } else {  // table over the pattern's own alphabet; for m > 255: of its 255-byte prefix
                 uint32_t k1 = 0;
-                const std::vector<uint8_t> dfa = sg::kmp_dfa_compressed(P, m, &k1);
+                const uint32_t w = std::min<uint32_t>(m, sg::kKmpDfaCompMaxM);
+                const std::vector<uint8_t> dfa = sg::kmp_dfa_compressed(P, w, &k1);
                 if (dfa.size() - 256 <= sg::kKmpDfaCompMaxBytes) {
                     blob.resize((blob.size() + 15) & ~size_t(15), 0);
                     append(dfa.data(), dfa.size());

@@ -815,7 +815,10 @@ __device__ __forceinline__ void kmp_dfa_chunk(const uint4& v, uint32_t j_base, u
 
 // Compressed table: the 16 column lookups colmap[c] do not depend on the state and are
 // issued together; the state chain then costs one dependent lookup per byte as above.
-template <bool CHECK>
+// MASK: instead of counting, return the chunk's hits as a bit mask in `hits` (bit q = the
+// automaton reached state m at byte q) — the long-pattern mode, where a hit is only a
+// 255-byte prefix match that still has to be verified.
+template <bool CHECK, bool MASK = false>
 __device__ __forceinline__ void kmp_dfac_chunk(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
                                                uint32_t& st, uint32_t& hits, uint32_t m, uint32_t k1,
                                                const uint8_t* __restrict__ colmap,
@@ -832,15 +835,20 @@ __device__ __forceinline__ void kmp_dfac_chunk(const uint4& v, uint32_t j_base, 
             const uint32_t j = j_base + q;
             const bool live = j >= j0 && j < jend;
             st = live ? nx : st;
-            hits += live && nx == m;
+            if (MASK) hits |= (live && nx == m) ? (1u << q) : 0u;
+            else hits += live && nx == m;
         } else {
             st = nx;
-            hits += nx == m;
+            if (MASK) hits |= (nx == m) ? (1u << q) : 0u;
+            else hits += nx == m;
         }
     }
 }
 
-// DFA: 0 failure links, 1 full 256-column table (m <= 95), 2 table over the pattern's alphabet
+// DFA: 0 failure links, 1 full 256-column table (m <= 64), 2 table over the pattern's own
+// alphabet (m <= 255), 3 the same table for the 255-byte PREFIX of a longer pattern: a
+// prefix hit is verified in memory (parked for wave_verify), as so.c / bndm.c do with their
+// 32-byte prefix for m > 32.  Every occurrence of P starts with an occurrence of its prefix.
 template <int DFA>
 __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
                                                 uint32_t dfa_off)
@@ -850,8 +858,9 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // LDS: [table][4 wave slabs]
     const uint32_t k1 = a.kmp_k1;
+    const uint32_t w = DFA == 3 ? kKmpDfaCompMaxM : m;  // length the automaton recognises
     const uint32_t table_bytes = DFA == 1 ? round16((m + 1) * 256)
-                               : DFA == 2 ? round16(256 + (m + 1) * k1) : round16(4 * m);
+                               : DFA >= 2 ? round16(256 + (w + 1) * k1) : round16(4 * m);
     uint8_t* slab = smem + table_bytes + wave * kRunSlab;
     const int16_t* gnext = reinterpret_cast<const int16_t*>(a.blob + kTableOff);
     if (DFA != 0) {
@@ -872,7 +881,7 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
     uint32_t hits = 0;
     const uint64_t run_first = a.s_begin / run_len;  // runs are cut on absolute offsets
     const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-    const uint32_t span = run_len + m - 1;           // bytes a run scans
+    const uint32_t span = run_len + w - 1;           // bytes a run scans
     const uint32_t nsteps = (span + 63) / 64;
     // group = 64 consecutive runs handled by one wave
     for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g * 64 < nruns; g += nwaves) {
@@ -891,7 +900,7 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
         const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
         const bool owner = my < nruns && sa < sb;
         const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
-        const uint32_t jend = owner ? (uint32_t)(sb - seg) + m - 1 : 0u;
+        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
 
         uint4 nx0 = *reinterpret_cast<const uint4*>(src[0]);
         uint4 nx1 = *reinterpret_cast<const uint4*>(src[1]);
@@ -899,6 +908,8 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
         uint4 nx3 = *reinterpret_cast<const uint4*>(src[3]);
         uint32_t st = 0;
         int sti = 0;
+        bool parked = false;  // DFA 3: first unverified prefix hit of this step
+        const uint8_t* parked_at = a.text;
         for (uint32_t k = 0; k < nsteps; ++k) {
             // park this step's 64 bytes of every run in the slab
             {
@@ -928,10 +939,29 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
                 } else if (DFA == 2) {
                     if (full) kmp_dfac_chunk<false>(v, j, j0, jend, st, hits, m, k1, dfa, dfa + 256);
                     else if (j < jend && j + 16 > j0) kmp_dfac_chunk<true>(v, j, j0, jend, st, hits, m, k1, dfa, dfa + 256);
+                } else if (DFA == 3) {
+                    uint32_t hm = 0;
+                    if (full) kmp_dfac_chunk<false, true>(v, j, j0, jend, st, hm, w, k1, dfa, dfa + 256);
+                    else if (j < jend && j + 16 > j0) kmp_dfac_chunk<true, true>(v, j, j0, jend, st, hm, w, k1, dfa, dfa + 256);
+                    while (hm) {  // the prefix ends at byte j+b: verify P[255..m)
+                        const uint32_t b = __builtin_ctz(hm);
+                        hm &= hm - 1;
+                        const uint8_t* rest = a.text + seg + j + b + 1;  // = text + start + w
+                        if (!parked) {
+                            parked = true;
+                            parked_at = rest;
+                        } else {
+                            hits += global_equal(rest, a.blob + w, m - w);
+                        }
+                    }
                 } else {
                     if (full) kmp_chunk<false>(v, j, j0, jend, sti, hits, (int)m, p0, next_m, tab);
                     else if (j < jend && j + 16 > j0) kmp_chunk<true>(v, j, j0, jend, sti, hits, (int)m, p0, next_m, tab);
                 }
+            }
+            if (DFA == 3 && __any(parked)) {  // wave-uniform point: at most one parked hit per lane
+                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
+                parked = false;
             }
         }
     }
@@ -1369,18 +1399,19 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
 static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream)
 {
     const uint32_t m = a.m;
+    const int dfa = m <= kKmpDfaMaxM ? 1 : !a.kmp_k1 ? 0 : m <= kKmpDfaCompMaxM ? 2 : 3;
+    const uint32_t w = dfa == 3 ? kKmpDfaCompMaxM : m;  // bytes re-scanned per run: w-1
     const uint64_t span = a.s_end - a.s_begin;
-    uint64_t L = 8ull * (m - 1);
+    uint64_t L = 8ull * (w - 1);
     const uint64_t fill = span / ((uint64_t)num_cus * 16 * 64);
     if (L > fill) L = fill;
-    if (L < 2ull * (m - 1)) L = 2ull * (m - 1);
+    if (L < 2ull * (w - 1)) L = 2ull * (w - 1);
     const uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 512;  // longer runs amortise the per-run set-up
     if (L < lmin) L = lmin;
     L = (L + 63) & ~63ull;
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
-    const int dfa = m <= kKmpDfaMaxM ? 1 : a.kmp_k1 ? 2 : 0;
-    const size_t table = dfa == 1 ? r16((m + 1) * 256) : dfa == 2 ? r16(256 + (m + 1) * a.kmp_k1) : r16(4 * m);
+    const size_t table = dfa == 1 ? r16((m + 1) * 256) : dfa >= 2 ? r16(256 + (w + 1) * a.kmp_k1) : r16(4 * m);
     const size_t lds = table + 4 * (size_t)kRunSlab;
     uint64_t grid = ((uint64_t)tr.count + 255) / 256;
     const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 4);
@@ -1391,6 +1422,9 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
                            (uint64_t)tr.count, dfa_off);
     else if (dfa == 2)
         hipLaunchKernelGGL(kmp_runs<2>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
+                           (uint64_t)tr.count, dfa_off);
+    else if (dfa == 3)
+        hipLaunchKernelGGL(kmp_runs<3>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
                            (uint64_t)tr.count, dfa_off);
     else
         hipLaunchKernelGGL(kmp_runs<0>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
