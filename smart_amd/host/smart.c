@@ -10,8 +10,11 @@
  *     system("./source/bin/<algo> shared ...") (smart.c:140-146);
  *   - pre/search times come back as out-parameters instead of two 8-byte shm
  *     segments (main.h:28-37).
- * Additions: -algo LIST, -data DIR, -gpu D, -gen (device-generated rand corpora
- * when the data directory has none), a GB/s column.
+ * Report files: TXT (-txt), LaTeX (-tex) and XML (always), in the formats of
+ * src/output.h:116-247; the HTML/PHP chart pages need SMART's RGraph assets and are
+ * not produced.
+ * Additions: -algo LIST, -data DIR, -gpu D, device-generated rand corpora when the
+ * data directory has none, a GB/s column (stdout) and <GBS> element (XML).
  *
  * Build: make -C smart_amd/host   (gcc, links ../csrc/libsmartgpu.so)
  */
@@ -50,7 +53,7 @@ struct options {
     long tsize;        /* -tsize in bytes (smart.c:416: 1 MiB) */
     int minlen, maxlen;
     const int *lengths;
-    int occ, pre, dif, std, txt;
+    int occ, pre, dif, std, txt, tex;
     int limit_ms;      /* -tb (smart.c:424: 300 ms) */
     int device;
     const char *data_dir;
@@ -77,6 +80,7 @@ static void usage(void)
     printf("\t-dif          prints the number the best and the worst running time\n");
     printf("\t-std          prints the standard deviations of the running times\n");
     printf("\t-txt          output results in txt tabular format\n");
+    printf("\t-tex          output results in latex tabular format\n");
     printf("\t-simple P T   executes a single run searching T (max 1000 chars) for occurrences of P (max 100 chars)\n");
     printf("\t-algo LIST    comma separated algorithms out of hor,bm,kmp,so,bndm,epsm (default: all six,\n");
     printf("\t              or the ones marked #1 in source/algorithms.h when that file exists)\n");
@@ -324,6 +328,81 @@ static void write_txt(const struct options *o, const char *corpus, const char *c
     printf("\tOUTPUT RUNNING TIMES %s (results/%s/%s.txt)\n", code, code, corpus);
 }
 
+/* results/<code>/<corpus>.tex: the same table as a LaTeX tabular
+ * (reference: outputLatex, src/output.h:153-194) */
+static void write_tex(const struct options *o, const char *corpus, const char *code,
+                      struct cell table[MAX_ALGOS][MAX_LENGTHS])
+{
+    char path[400];
+    mkdir("results", 0775);
+    snprintf(path, sizeof path, "results/%s", code);
+    mkdir(path, 0775);
+    snprintf(path, sizeof path, "results/%s/%s.tex", code, corpus);
+    FILE *fp = fopen(path, "w");
+    if (!fp) return;
+    printf("\tSaving data on %s/%s.tex\n", code, corpus);
+    fprintf(fp, "\\begin{tabular}{|l|");
+    for (int il = 0; o->lengths[il] > 0; ++il)
+        if (o->lengths[il] >= o->minlen && o->lengths[il] <= o->maxlen) fprintf(fp, "l");
+    fprintf(fp, "|}\n\\hline\n$m$");
+    for (int il = 0; o->lengths[il] > 0; ++il)
+        if (o->lengths[il] >= o->minlen && o->lengths[il] <= o->maxlen) fprintf(fp, " & $%d$", o->lengths[il]);
+    fprintf(fp, "\\\\\n");
+    for (int ia = 0; ia < o->nalgos; ++ia) {
+        char name[32];
+        upper(name, smartgpu_algo_name(o->algos[ia]));
+        fprintf(fp, "\\textsc{%s}", name);
+        for (int il = 0; o->lengths[il] > 0; ++il) {
+            if (o->lengths[il] < o->minlen || o->lengths[il] > o->maxlen) continue;
+            if (table[ia][il].mean > 0) fprintf(fp, " & %.2f", table[ia][il].mean);
+            else fprintf(fp, " & -");
+        }
+        fprintf(fp, "\\\\\n");
+    }
+    fprintf(fp, "\\hline\n\\end{tabular}");
+    fclose(fp);
+}
+
+/* results/<code>/<corpus>.xml (reference: outputXML, src/output.h:196-247): per algorithm
+ * one <DATA><SEARCH>ms</SEARCH></DATA> per length, then the best time per length.  An
+ * aborted cell is a single <DATA>-</DATA> (the reference prints that AND a 0.00 block);
+ * <GBS> (GB/s of text scanned) is this harness' addition. */
+static void write_xml(const struct options *o, const char *corpus, const char *code,
+                      struct cell table[MAX_ALGOS][MAX_LENGTHS])
+{
+    char path[400];
+    mkdir("results", 0775);
+    snprintf(path, sizeof path, "results/%s", code);
+    mkdir(path, 0775);
+    snprintf(path, sizeof path, "results/%s/%s.xml", code, corpus);
+    FILE *fp = fopen(path, "w");
+    if (!fp) return;
+    printf("\tSaving data on %s/%s.xml\n", code, corpus);
+    fprintf(fp, "<RESULTS>\n\t<CODE>%s</CODE>\n\t<TEXT>%s</TEXT>\n", code, corpus);
+    for (int ia = 0; ia < o->nalgos; ++ia) {
+        char name[32];
+        upper(name, smartgpu_algo_name(o->algos[ia]));
+        fprintf(fp, "\t<ALGO>\n\t\t<NAME>%s</NAME>\n", name);
+        for (int il = 0; o->lengths[il] > 0; ++il) {
+            if (o->lengths[il] < o->minlen || o->lengths[il] > o->maxlen) continue;
+            const struct cell *c = &table[ia][il];
+            if (c->mean <= 0) { fprintf(fp, "\t\t<DATA>-</DATA>\n"); continue; }
+            fprintf(fp, "\t\t<DATA>\n\t\t\t<SEARCH>%.2f</SEARCH>\n\t\t\t<GBS>%.1f</GBS>\n\t\t</DATA>\n", c->mean, c->gbs);
+        }
+        fprintf(fp, "\t</ALGO>\n");
+    }
+    fprintf(fp, "\t<BEST>\n");
+    for (int il = 0; o->lengths[il] > 0; ++il) {
+        if (o->lengths[il] < o->minlen || o->lengths[il] > o->maxlen) continue;
+        double best = 999999.0;
+        for (int ia = 0; ia < o->nalgos; ++ia)
+            if (table[ia][il].mean > 0 && table[ia][il].mean < best) best = table[ia][il].mean;
+        fprintf(fp, "\t\t<DATA>%.2f</DATA>\n", best);
+    }
+    fprintf(fp, "\t</BEST>\n</RESULTS>");
+    fclose(fp);
+}
+
 int main(int argc, char **argv)
 {
     struct options o;
@@ -367,7 +446,8 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "-dif")) o.dif = 1;
         else if (!strcmp(a, "-std")) o.std = 1;
         else if (!strcmp(a, "-txt")) o.txt = 1;
-        else if (!strcmp(a, "-tex") || !strcmp(a, "-php")) { /* report writers outside the hot path */ }
+        else if (!strcmp(a, "-tex")) o.tex = 1;
+        else if (!strcmp(a, "-php")) { /* PHP/HTML chart pages need SMART's RGraph assets: not provided */ }
         else if (!strcmp(a, "-short")) o.lengths = LEN_SHORT;
         else if (!strcmp(a, "-vshort")) o.lengths = LEN_VERY_SHORT;
         else if (!strcmp(a, "-data")) { if (!has1) { printf("%s", bad); return 0; } o.data_dir = argv[++i]; }
@@ -459,6 +539,8 @@ int main(int argc, char **argv)
         memset(table, 0, sizeof table);
         run_corpus(&o, corpus, T, n, text, code, table);
         if (o.txt) write_txt(&o, corpus, code, table);
+        write_xml(&o, corpus, code, table); /* always, as smart.c:388 */
+        if (o.tex) write_tex(&o, corpus, code, table);
         smartgpu_text_free(text);
     }
     free(T);

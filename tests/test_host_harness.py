@@ -50,7 +50,7 @@ def test_reference_cases_through_plugin_shape(algo):
 @pytest.mark.gpu
 def test_smart_report_lines(tmp_path):
     r = run("smart", "-text", "rand128", "-plen", "32", "32", "-pset", "5", "-occ", "-pre", "-dif", "-std", "-txt",
-            cwd=str(tmp_path))
+            "-tex", cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
     assert "Searching for a set of 5 patterns with length 32" in out
@@ -61,6 +61,10 @@ def test_smart_report_lines(tmp_path):
         assert re.search(r"\d+\.\d\d \+ \d+\.\d\d ms", line[0])
     table = list((tmp_path / "results").glob("EXP*/rand128.txt"))
     assert table and table[0].read_text().startswith("HOR")
+    xml = list((tmp_path / "results").glob("EXP*/rand128.xml"))[0].read_text()
+    assert xml.startswith("<RESULTS>") and xml.count("<NAME>") == 6 and "<SEARCH>" in xml and "<BEST>" in xml
+    tex = list((tmp_path / "results").glob("EXP*/rand128.tex"))[0].read_text()
+    assert tex.startswith("\\begin{tabular}{|l|l|}") and "\\textsc{HOR} & " in tex and tex.endswith("\\end{tabular}")
     # -simple: the reference's own example (SURVEY.md §5 hazard 3 segfaults EPSM there)
     r = run("smart", "-simple", "aba", "ababababab", "-pset", "1", "-occ", cwd=str(tmp_path))
     assert r.stdout.count("occ 4") == 6, r.stdout

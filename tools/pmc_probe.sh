@@ -17,7 +17,7 @@ out=sys.argv[1]
 for f in sorted(glob.glob(out+"/pmc_*/**/*counter_collection.csv", recursive=True)):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "_scan" in r["Kernel_Name"]:
+        if "_scan" in r["Kernel_Name"] or "_runs" in r["Kernel_Name"]:
             agg[(r["Kernel_Name"].split("(")[0][-20:], r["Counter_Name"])].append(float(r["Counter_Value"]))
     for k,v in sorted(agg.items()): print("%-22s %-28s n=%d mean=%.1f"%(k[0],k[1],len(v),sum(v)/len(v)))
 PY
