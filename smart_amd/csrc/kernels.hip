@@ -1417,6 +1417,10 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 4);
     if (grid > cap) grid = cap;
     const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));
+    if (lds > 64 * 1024) {  // large own-alphabet tables need the opt-in for > 64 KiB of dynamic LDS
+        const void* fn = dfa == 2 ? reinterpret_cast<const void*>(kmp_runs<2>) : reinterpret_cast<const void*>(kmp_runs<3>);
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (dfa == 1)
         hipLaunchKernelGGL(kmp_runs<1>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
                            (uint64_t)tr.count, dfa_off);

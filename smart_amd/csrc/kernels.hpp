@@ -20,7 +20,7 @@ constexpr uint32_t kPatternBytes = 4224;        // pattern slot in the plan blob
 constexpr int kResultSlots = 4096;
 constexpr uint32_t kKmpDfaMaxM = 64;            // KMP: (m+1)*256-byte transition table kept in LDS up to this m
 constexpr uint32_t kKmpDfaCompMaxM = 255;       // ... and a table over the pattern's own alphabet up to this m,
-constexpr uint32_t kKmpDfaCompMaxBytes = 40960; //     if it fits this many bytes (u8 states)
+constexpr uint32_t kKmpDfaCompMaxBytes = 57344; //     if it fits this many bytes (u8 states)
 
 // What every scan kernel receives.
 struct ScanArgs {
