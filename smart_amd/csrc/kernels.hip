@@ -1,28 +1,32 @@
 // kernels.hip — gfx950 (CDNA4, wave64) scan kernels for exact string matching.
 //
-// One kernel per SMART algorithm name; all of them compute the same function
+// Every kernel computes the same function
 //     count(P,T) = |{ s in [s_begin, s_end) : T[s..s+m) == P }|
-// and differ in the per-lane scan strategy and the tables they stage in LDS.
+// (overlapping occurrences count) and differs in the per-lane scan strategy and in
+// the tables it stages in LDS.  Three families:
 //
-// Common structure of the LDS-tiled kernels
-//   * the text is cut into tiles of TB = THREADS*L bytes on ABSOLUTE text
-//     offsets (tile t = bytes [t*TB, (t+1)*TB)), so every tile load is 16-byte
-//     aligned and fully coalesced (global_load_dwordx4, 1 KiB per wave-load);
-//   * a workgroup stages tile + halo into LDS, then each lane owns a contiguous
-//     run of L positions inside the tile and runs the algorithm's own loop
-//     against LDS with the algorithm's own tables (also in LDS);
-//   * restarting the algorithm at a lane/tile/GPU boundary preserves the count
-//     (SURVEY.md §7 restart table): skip algorithms carry no state between
-//     windows, the automata restart in their initial state and re-scan m-1 bytes;
-//   * per-lane hit counters are summed across the 64-lane wave and one 64-bit
-//     atomic per wave goes to the result slot.
+//  1. LDS TILES — the skip algorithms HOR, BM, BNDM (hor_scan, bm_scan, bndm_scan).
+//     The text is cut into tiles of TB = THREADS*L bytes on ABSOLUTE text offsets, so
+//     every tile load is 16-byte aligned and coalesced (global_load_dwordx4 nt, 1 KiB
+//     per wave-load); tile t+1 is prefetched into registers while the lanes walk tile
+//     t.  Tiles are indexed by window END position e = s+m-1 with a BACK halo of
+//     H = min(m-1, 16) bytes: the byte that drives the shift, T[e], is always in the
+//     tile; a lane verifies right-to-left through the halo by itself and — only for
+//     m-1 > H and only after H+1 bytes matched — parks the window for a
+//     wave-cooperative comparison of the rest (wave_verify).
+//  2. RUNS THROUGH LDS SLABS — the serial automata SO and KMP (so_runs, kmp_runs).
+//     A lane owns a run of >= 512 start positions; the wave fetches the next 64 bytes
+//     of each of its 64 runs with four coalesced loads into its own LDS slab and every
+//     lane reads its run back.  No workgroup barrier.
+//  3. PACKED — EPSM, and the short-pattern / tiny-shift regime of the skip algorithms
+//     (packed_scan): every alignment is compared from registers, no LDS.
 //
-// Skip kernels (HOR, BM, BNDM) index tiles by window END position e = s+m-1 and
-// keep a BACK halo of H = min(m-1, 16) bytes in LDS: the byte that drives the
-// shift, T[e], is always in the tile; a lane verifies right-to-left through the
-// halo by itself and — only for m-1 > H and only after H+1 bytes matched — parks
-// the window for a wave-cooperative comparison of the rest (wave_verify).  Serial kernels (SO, KMP) index tiles by START position and
-// keep a forward halo.
+// Restarting an algorithm at a lane / tile / run / GPU boundary preserves the count
+// (SURVEY.md §7 restart table): skip algorithms carry no state between windows, the
+// automata restart in their initial state and re-scan w-1 bytes.  Per-lane hit
+// counters are summed across the 64-lane wave; one 64-bit atomic per wave.
+// so_scan / kmp_scan (LDS tiles for the serial automata) and hor_scan_bp (bank-private
+// LDS layout) are earlier designs kept selectable for A/B runs (smartgpu_tune).
 #include "kernels.hpp"
 
 #include "../../include/smartgpu.h"
