@@ -131,6 +131,28 @@ int smartgpu_plan_reset(smartgpu_plan *p);
  * reduces across GPUs with RCCL.  NULL restores the plan's own slots. */
 int smartgpu_plan_set_result_buffer(smartgpu_plan *p, void *device_u64, int nslots);
 
+/* ---- one process, several GPUs (the 8 GPUs of a node) ---------------------------- */
+/* A text sharded by byte offset over `ngpus` devices of this process: device g owns the
+ * start positions [g*n/k, (g+1)*n/k) and holds SMARTGPU_XSIZE extra bytes, so any pattern
+ * length can be searched without an exchange step.  `devices` lists the
+ * device ordinals (NULL = 0..ngpus-1). */
+typedef struct smartgpu_mtext smartgpu_mtext;
+smartgpu_mtext *smartgpu_mtext_upload(const void *host, uint64_t n, int ngpus, const int *devices);
+smartgpu_mtext *smartgpu_mtext_generate(uint64_t seed, int sigma, uint64_t n, int ngpus, const int *devices);
+void smartgpu_mtext_free(smartgpu_mtext *t);
+uint64_t smartgpu_mtext_length(const smartgpu_mtext *t);
+int smartgpu_mtext_ngpus(const smartgpu_mtext *t);
+/* Searches every shard concurrently (one stream per device) and sums the shard counts.
+ * reduce = SMARTGPU_REDUCE_RCCL: ncclAllReduce(sum, uint64) over the devices' streams (RCCL
+ * over xGMI; the devices must be distinct), then one 8-byte read-back;
+ * reduce = SMARTGPU_REDUCE_HOST: eight-byte read-backs added on the host (also allows the
+ * same device to appear more than once, which is how the shard arithmetic is tested on a
+ * one-GPU box).  *run_ms covers launches + reduction + read-back. */
+#define SMARTGPU_REDUCE_RCCL 0
+#define SMARTGPU_REDUCE_HOST 1
+int smartgpu_msearch64(int algo, const uint8_t *P, uint32_t m, smartgpu_mtext *text, int reduce,
+                       uint64_t *count, double *pre_ms, double *run_ms);
+
 /* ---- stream timing (hipEvents on the stream the kernels run on) ------------ */
 int smartgpu_stream_mark(int device, int which /* 0 = begin, 1 = end */);
 int smartgpu_stream_elapsed_ms(int device, double *ms); /* waits for mark 1 */

@@ -7,6 +7,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdarg>
@@ -621,6 +623,207 @@ int smartgpu_kmp_search(const unsigned char* P, int m, const unsigned char* T, i
 int smartgpu_so_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_SO, P, m, T, n); }
 int smartgpu_bndm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_BNDM, P, m, T, n); }
 int smartgpu_epsm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_EPSM, P, m, T, n); }
+
+/* ---- one process, several GPUs ------------------------------------------ */
+}  // extern "C"
+
+namespace {
+
+// RCCL is loaded on first use (dlopen), so the library itself has no link-time
+// dependency on it; only the multi-GPU reduce needs it.
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t s) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    bool load()
+    {
+        if (lib) return true;
+        lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { set_error("cannot load librccl.so: %s", dlerror()); return false; }
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd) {
+            set_error("librccl.so lacks an expected symbol");
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclUint64 = 5, kNcclSum = 0;  // rccl.h: ncclUint64, ncclSum
+
+}  // namespace
+
+struct smartgpu_mtext {
+    uint64_t n = 0;
+    std::vector<int> devices;
+    std::vector<smartgpu_text*> shards;   // shard g = bytes [begin[g], begin[g+1] + overlap)
+    std::vector<uint64_t> begin;          // k+1 entries, start-position ownership
+    std::vector<void*> comms;             // RCCL communicators, created on first RCCL reduce
+    std::vector<unsigned long long*> sums;  // per-device 8-byte reduce buffers
+};
+
+namespace {
+
+smartgpu_mtext* mtext_new(uint64_t n, int ngpus, const int* devices)
+{
+    if (ngpus < 1 || ngpus > kMaxDevices) { set_error("ngpus %d outside [1,%d]", ngpus, kMaxDevices); return nullptr; }
+    smartgpu_mtext* t = new smartgpu_mtext;
+    t->n = n;
+    for (int g = 0; g < ngpus; ++g) t->devices.push_back(devices ? devices[g] : g);
+    for (int g = 0; g <= ngpus; ++g) t->begin.push_back(n / ngpus * g + std::min<uint64_t>(g, n % ngpus));
+    return t;
+}
+
+// bytes shard g has to hold: its own starts plus XSIZE-1 bytes of the next shards
+void shard_span(const smartgpu_mtext* t, int g, uint64_t* off, uint64_t* len)
+{
+    *off = t->begin[g];
+    const uint64_t end = std::min<uint64_t>(t->n, t->begin[g + 1] + SMARTGPU_XSIZE - 1);
+    *len = end - *off;
+}
+
+}  // namespace
+
+extern "C" {
+
+smartgpu_mtext* smartgpu_mtext_upload(const void* host, uint64_t n, int ngpus, const int* devices)
+{
+    if (!host && n) { set_error("host pointer is NULL"); return nullptr; }
+    smartgpu_mtext* t = mtext_new(n, ngpus, devices);
+    if (!t) return nullptr;
+    for (int g = 0; g < ngpus; ++g) {
+        uint64_t off, len;
+        shard_span(t, g, &off, &len);
+        smartgpu_text* s = smartgpu_text_upload(static_cast<const uint8_t*>(host) + off, len, t->devices[g]);
+        if (!s) { smartgpu_mtext_free(t); return nullptr; }
+        t->shards.push_back(s);
+    }
+    return t;
+}
+
+smartgpu_mtext* smartgpu_mtext_generate(uint64_t seed, int sigma, uint64_t n, int ngpus, const int* devices)
+{
+    smartgpu_mtext* t = mtext_new(n, ngpus, devices);
+    if (!t) return nullptr;
+    for (int g = 0; g < ngpus; ++g) {
+        uint64_t off, len;
+        shard_span(t, g, &off, &len);
+        smartgpu_text* s = smartgpu_text_generate(seed, sigma, off, len, t->devices[g]);
+        if (!s) { smartgpu_mtext_free(t); return nullptr; }
+        t->shards.push_back(s);
+    }
+    return t;
+}
+
+void smartgpu_mtext_free(smartgpu_mtext* t)
+{
+    if (!t) return;
+    for (smartgpu_text* s : t->shards) smartgpu_text_free(s);
+    for (size_t g = 0; g < t->sums.size(); ++g) {
+        hipSetDevice(t->devices[g]);
+        hipFree(t->sums[g]);
+    }
+    for (void* c : t->comms)
+        if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
+    delete t;
+}
+
+uint64_t smartgpu_mtext_length(const smartgpu_mtext* t) { return t ? t->n : 0; }
+int smartgpu_mtext_ngpus(const smartgpu_mtext* t) { return t ? static_cast<int>(t->devices.size()) : 0; }
+
+int smartgpu_msearch64(int algo, const uint8_t* P, uint32_t m, smartgpu_mtext* text, int reduce,
+                       uint64_t* count, double* pre_ms, double* run_ms)
+{
+    if (!text) { set_error("text handle is NULL"); return SMARTGPU_ERR_ARG; }
+    if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS) { set_error("unknown algorithm id %d", algo); return SMARTGPU_ERR_ARG; }
+    if (!P || m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return SMARTGPU_ERR_ARG; }
+    const int k = static_cast<int>(text->devices.size());
+    // preprocessing: the tables are placed on every device
+    const double t_pre = now_ms();
+    std::vector<smartgpu_plan*> plans(k, nullptr);
+    auto cleanup = [&]() { for (smartgpu_plan* p : plans) smartgpu_plan_free(p); };
+    for (int g = 0; g < k; ++g) {
+        plans[g] = smartgpu_plan_create(algo, P, m, text->devices[g]);
+        if (!plans[g]) { cleanup(); return SMARTGPU_ERR_HIP; }
+    }
+    const double pre = now_ms() - t_pre;
+    if (reduce == SMARTGPU_REDUCE_RCCL) {
+        if (text->comms.empty()) {
+            if (!g_rccl.load()) { cleanup(); return SMARTGPU_ERR_HIP; }
+            text->comms.assign(k, nullptr);
+            if (g_rccl.CommInitAll(text->comms.data(), k, text->devices.data()) != 0) {
+                set_error("ncclCommInitAll failed (devices must be distinct)");
+                text->comms.clear();
+                cleanup();
+                return SMARTGPU_ERR_HIP;
+            }
+        }
+        if (text->sums.empty()) {
+            text->sums.assign(k, nullptr);
+            for (int g = 0; g < k; ++g) {
+                hipSetDevice(text->devices[g]);
+                if (hipMalloc(reinterpret_cast<void**>(&text->sums[g]), 8) != hipSuccess) {
+                    set_error("hipMalloc of the reduce buffer failed");
+                    cleanup();
+                    return SMARTGPU_ERR_NOMEM;
+                }
+            }
+        }
+    }
+    // searching: every shard on its own device / stream, concurrently
+    const double t_run = now_ms();
+    int rc = SMARTGPU_OK;
+    for (int g = 0; g < k && rc == SMARTGPU_OK; ++g) {
+        // shard g counts the starts it owns: its first (begin[g+1]-begin[g]) positions
+        const uint64_t own = text->begin[g + 1] - text->begin[g];
+        const uint64_t have = smartgpu_text_length(text->shards[g]);
+        const uint64_t span = std::min<uint64_t>(have, own + m - 1);
+        rc = smartgpu_plan_launch(plans[g], text->shards[g], 0, span, 0, 0);
+    }
+    uint64_t total = 0;
+    if (rc == SMARTGPU_OK && reduce == SMARTGPU_REDUCE_RCCL) {
+        g_rccl.GroupStart();
+        for (int g = 0; g < k; ++g) {
+            DeviceCtx* d = device_ctx(text->devices[g]);
+            g_rccl.AllReduce(plans[g]->slot_ptr(0), text->sums[g], 1, kNcclUint64, kNcclSum, text->comms[g], d->stream);
+        }
+        if (g_rccl.GroupEnd() != 0) { set_error("RCCL all-reduce failed"); rc = SMARTGPU_ERR_HIP; }
+        if (rc == SMARTGPU_OK) {
+            DeviceCtx* d0 = device_ctx(text->devices[0]);
+            if (hipMemcpyAsync(d0->pinned_count, text->sums[0], 8, hipMemcpyDeviceToHost, d0->stream) != hipSuccess ||
+                hipStreamSynchronize(d0->stream) != hipSuccess) {
+                set_error("read-back of the reduced count failed");
+                rc = SMARTGPU_ERR_HIP;
+            } else {
+                total = *d0->pinned_count;
+            }
+            for (int g = 1; g < k; ++g) smartgpu_device_sync(text->devices[g]);
+        }
+    } else if (rc == SMARTGPU_OK) {
+        for (int g = 0; g < k && rc == SMARTGPU_OK; ++g) {
+            uint64_t c = 0;
+            rc = smartgpu_plan_result(plans[g], 0, &c, nullptr);
+            total += c;
+        }
+    }
+    const double run = now_ms() - t_run;
+    cleanup();
+    if (rc != SMARTGPU_OK) return rc;
+    g_last_pre_ms = pre;
+    g_last_run_ms = run;
+    if (count) *count = total;
+    if (pre_ms) *pre_ms = pre;
+    if (run_ms) *run_ms = run;
+    return SMARTGPU_OK;
+}
 
 /* ---- table export (tests) ---------------------------------------------- */
 int smartgpu_build_table(int which, const uint8_t* P, uint32_t m, int32_t* out, uint32_t cap)

@@ -66,6 +66,12 @@ def lib():
         "smartgpu_stream_elapsed_ms": (i32, [i32, C.POINTER(C.c_double)]),
         "smartgpu_stream_handle": (vp, [i32]),
         "smartgpu_tune": (i32, [i32, i32]),
+        "smartgpu_mtext_upload": (vp, [vp, u64, i32, vp]),
+        "smartgpu_mtext_generate": (vp, [u64, i32, u64, i32, vp]),
+        "smartgpu_mtext_free": (None, [vp]),
+        "smartgpu_mtext_length": (u64, [vp]),
+        "smartgpu_mtext_ngpus": (i32, [vp]),
+        "smartgpu_msearch64": (i32, [i32, vp, u32, vp, i32, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "smartgpu_probe_read_ms": (i32, [vp, i32, C.POINTER(C.c_double)]),
     }
     for a in ALGOS:
@@ -199,6 +205,58 @@ class Plan:
     def free(self):
         if self._h:
             lib().smartgpu_plan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class MultiText:
+    """A text sharded over several GPUs of this process (smartgpu_mtext_*)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise _err("mtext")
+        self._h = handle
+
+    @staticmethod
+    def _devs(devices):
+        if devices is None:
+            return None, None
+        arr = (C.c_int * len(devices))(*devices)
+        return arr, C.cast(arr, C.c_void_p)
+
+    @classmethod
+    def upload(cls, data, ngpus, devices=None):
+        data = _u8(data)
+        keep, ptr = cls._devs(devices)
+        return cls(lib().smartgpu_mtext_upload(data.ctypes.data, len(data), ngpus, ptr))
+
+    @classmethod
+    def generate(cls, seed, sigma, n, ngpus, devices=None):
+        keep, ptr = cls._devs(devices)
+        return cls(lib().smartgpu_mtext_generate(seed, sigma, n, ngpus, ptr))
+
+    def __len__(self):
+        return int(lib().smartgpu_mtext_length(self._h))
+
+    def search(self, algo, P, reduce="rccl"):
+        P = _u8(P)
+        c = C.c_uint64(0)
+        pre = C.c_double(0.0)
+        run = C.c_double(0.0)
+        rc = lib().smartgpu_msearch64(algo_id(algo), P.ctypes.data, len(P), self._h, 0 if reduce == "rccl" else 1,
+                                      C.byref(c), C.byref(pre), C.byref(run))
+        if rc != 0:
+            raise _err("msearch64(%s) rc=%d" % (algo, rc))
+        return int(c.value), float(pre.value), float(run.value)
+
+    def free(self):
+        if self._h:
+            lib().smartgpu_mtext_free(self._h)
             self._h = None
 
     def __del__(self):

@@ -56,6 +56,7 @@ struct options {
     int occ, pre, dif, std, txt, tex;
     int limit_ms;      /* -tb (smart.c:424: 300 ms) */
     int device;
+    int gpus;          /* -gpus k: shard the text over k GPUs of this process, RCCL sum of the counts */
     const char *data_dir;
     char text_arg[256];
     char simple_p[128], simple_t[1100];
@@ -86,6 +87,7 @@ static void usage(void)
     printf("\t              or the ones marked #1 in source/algorithms.h when that file exists)\n");
     printf("\t-data DIR     directory holding <corpus>/index.txt (default \"data\")\n");
     printf("\t-gpu D        device ordinal (default 0)\n");
+    printf("\t-gpus K       shard the text by byte offset over GPUs 0..K-1 (RCCL sum of the counts)\n");
     printf("\t-h            gives this help list\n\n");
 }
 
@@ -188,7 +190,8 @@ struct cell { double mean, pre, best, worst, std, gbs; int status; };
 /* One corpus: every pattern length x every algorithm x `runs` patterns
  * (reference: run_setting, src/smart.c:178-402). */
 static void run_corpus(const struct options *o, const char *corpus, const unsigned char *T, long n,
-                       smartgpu_text *text, const char *code, struct cell table[MAX_ALGOS][MAX_LENGTHS])
+                       smartgpu_text *text, smartgpu_mtext *mtext, const char *code,
+                       struct cell table[MAX_ALGOS][MAX_LENGTHS])
 {
     unsigned char **pats = malloc(sizeof(*pats) * (size_t)o->runs);
     for (int i = 0; i < o->runs; ++i) pats[i] = malloc(XSIZE + 1);
@@ -235,7 +238,8 @@ static void run_corpus(const struct options *o, const char *corpus, const unsign
                 fflush(stdout);
                 uint64_t count = 0;
                 double pre_ms = 0, run_ms = 0;
-                int rc = smartgpu_search64(algo, pats[k - 1], (uint32_t)m, text, 0, (uint64_t)n, &count, &pre_ms, &run_ms);
+                int rc = mtext ? smartgpu_msearch64(algo, pats[k - 1], (uint32_t)m, mtext, SMARTGPU_REDUCE_RCCL, &count, &pre_ms, &run_ms)
+                               : smartgpu_search64(algo, pats[k - 1], (uint32_t)m, text, 0, (uint64_t)n, &count, &pre_ms, &run_ms);
                 long long occur = rc == SMARTGPU_OK ? (long long)count : -1;
                 double e = o->pre ? run_ms : run_ms + pre_ms; /* smart.c:323 */
                 sample[k] = e;
@@ -452,6 +456,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "-vshort")) o.lengths = LEN_VERY_SHORT;
         else if (!strcmp(a, "-data")) { if (!has1) { printf("%s", bad); return 0; } o.data_dir = argv[++i]; }
         else if (!strcmp(a, "-gpu")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.device = atoi(argv[++i]); }
+        else if (!strcmp(a, "-gpus")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.gpus = atoi(argv[++i]); }
         else if (!strcmp(a, "-algo")) {
             if (!has1) { printf("%s", bad); return 0; }
             char list[256];
@@ -472,6 +477,10 @@ int main(int argc, char **argv)
         if (n > 0) o.nalgos = n;
         else for (int i = 0; i < MAX_ALGOS; ++i) o.algos[o.nalgos++] = i;
     }
+    if (o.gpus > smartgpu_device_count()) {
+        fprintf(stderr, "smart: -gpus %d but only %d GPU(s) visible\n", o.gpus, smartgpu_device_count());
+        return 1;
+    }
     if (smartgpu_device_count() <= o.device) {
         fprintf(stderr, "smart: no usable GPU %d: %s\n", o.device, smartgpu_last_error());
         return 1;
@@ -491,7 +500,7 @@ int main(int argc, char **argv)
         printf("\tStarting experimental tests with code %s\n", code);
         smartgpu_text *text = smartgpu_text_upload(o.simple_t, (uint64_t)n, o.device);
         if (!text) { fprintf(stderr, "smart: %s\n", smartgpu_last_error()); return 1; }
-        run_corpus(&o, "", (const unsigned char *)o.simple_t, n, text, code, table);
+        run_corpus(&o, "", (const unsigned char *)o.simple_t, n, text, NULL, code, table);
         smartgpu_text_free(text);
         return 0;
     }
@@ -530,6 +539,12 @@ int main(int argc, char **argv)
             continue;
         }
         if (!text) { fprintf(stderr, "smart: %s\n", smartgpu_last_error()); continue; }
+        smartgpu_mtext *mtext = NULL;
+        if (o.gpus > 1) {  /* the same bytes, sharded over GPUs 0..gpus-1 */
+            mtext = smartgpu_mtext_upload(T, (uint64_t)n, o.gpus, NULL);
+            if (!mtext) { fprintf(stderr, "smart: %s\n", smartgpu_last_error()); smartgpu_text_free(text); continue; }
+            printf("\tText sharded over %d GPUs (%ld bytes each, %d bytes overlap)\n", o.gpus, n / o.gpus, SMARTGPU_XSIZE - 1);
+        }
         alphabet_report(T, n);
         printf("\tText buffer of dimension %ld byte\n", n);
         time_t now = time(NULL);
@@ -537,7 +552,8 @@ int main(int argc, char **argv)
         strftime(stamp, sizeof stamp, "%Y:%m:%d %H:%M:%S", localtime(&now));
         printf("\tExperimental tests started on %s\n", stamp);
         memset(table, 0, sizeof table);
-        run_corpus(&o, corpus, T, n, text, code, table);
+        run_corpus(&o, corpus, T, n, text, mtext, code, table);
+        smartgpu_mtext_free(mtext);
         if (o.txt) write_txt(&o, corpus, code, table);
         write_xml(&o, corpus, code, table); /* always, as smart.c:388 */
         if (o.tex) write_tex(&o, corpus, code, table);

@@ -304,3 +304,32 @@ def test_text_beyond_4gib():
             assert len(set(sub.values())) == 1 and sub["hor"] >= inside, (m, k, sub)
             if m >= 40:
                 assert sub["hor"] == inside, (m, k, sub)
+
+
+def test_multi_gpu_text_in_one_process(oracle):
+    """smartgpu_mtext_*: shards by start offset with an overlap, per-shard searches, one
+    reduction.  On a one-GPU box the shard arithmetic is exercised by listing device 0
+    several times (host reduce); the RCCL all-reduce path runs with one rank."""
+    from smart_amd import MultiText
+    T = oracle.gen_text(99, 4, 0, 1_000_003)
+    for k in (1, 2, 3, 8):
+        mt = MultiText.upload(T, k, devices=[0] * k)
+        assert len(mt) == len(T)
+        for m in (1, 2, 31, 300, 4200):
+            P = T[333331:333331 + m]
+            want = oracle.search("epsm", P, T)
+            for algo in ("hor", "kmp", "so"):
+                assert mt.search(algo, P, reduce="host")[0] == want, (k, m, algo)
+        mt.free()
+    mt = MultiText.generate(SEED2, 128, 50_000_000, 1)
+    ref = Text.generate(SEED2, 128, 50_000_000)
+    P = ref.pattern(40_000_000, 64)
+    c, pre_ms, run_ms = mt.search("bm", P, reduce="rccl")
+    assert c == smart_amd.search("bm", P, ref)[0] >= 1 and run_ms > 0
+    # a pattern that straddles a shard boundary is owned by exactly one shard
+    n = 3_000_000
+    mt = MultiText.generate(SEED2, 128, n, 3, devices=[0, 0, 0])
+    ref = Text.generate(SEED2, 128, n)
+    for m in (2, 100, 4000):
+        P = ref.pattern(1_000_000 - m // 2, m)  # shard 0/1 boundary is at 1,000,000
+        assert mt.search("hor", P, reduce="host")[0] == smart_amd.search("hor", P, ref)[0] >= 1
