@@ -66,29 +66,28 @@ struct options {
 
 static void usage(void)
 {
-    printf("\tThis is a basic help guide for using the tool\n\n");
-    printf("\t-pset N       computes running times as the mean of N runs (default 500)\n");
-    printf("\t-tsize S      set the upper bound dimension (in Mb) of the text used for experimental results (default 1Mb)\n");
-    printf("\t-plen L U     test only patterns with a length between L and U (included).\n");
-    printf("\t-text F       performs experimental results using text buffer F (mandatory unless you use the -simple parameter)\n");
-    printf("\t              Use option \"all\" to performe experimental results using all text buffers.\n");
-    printf("\t              Use the style A-B-C to performe experimental results using multiple text buffers.\n");
-    printf("\t-short        computes experimental results using short length patterns (from 2 to 32)\n");
-    printf("\t-vshort       computes experimental results using very short length patterns (from 1 to 16)\n");
-    printf("\t-occ          prints the average number of occurrences\n");
-    printf("\t-pre          computes separately preprocessing times and searching times\n");
-    printf("\t-tb L         set to L the upper bound for any wort case running time (in ms). The default value is 300 ms\n");
-    printf("\t-dif          prints the number the best and the worst running time\n");
-    printf("\t-std          prints the standard deviations of the running times\n");
-    printf("\t-txt          output results in txt tabular format\n");
-    printf("\t-tex          output results in latex tabular format\n");
-    printf("\t-simple P T   executes a single run searching T (max 1000 chars) for occurrences of P (max 100 chars)\n");
+    /* the flags of the reference driver (src/smart.c:48-71), described in this project's words */
+    printf("\tsmart - exact string matching benchmark on the MI355X engine\n\n");
+    printf("\t-pset N       number of patterns per length; times are means over them (default 500)\n");
+    printf("\t-tsize S      use at most S MiB of the corpus as the text (default 1)\n");
+    printf("\t-plen L U     only pattern lengths in [L, U]\n");
+    printf("\t-text F       corpus to search (required unless -simple): a name, \"all\", or a list A-B-C\n");
+    printf("\t-short        pattern lengths 2,4,...,32 instead of 2,4,8,...,4096\n");
+    printf("\t-vshort       pattern lengths 1..16\n");
+    printf("\t-occ          also print the mean number of occurrences\n");
+    printf("\t-pre          report preprocessing and searching times separately\n");
+    printf("\t-tb L         give up on an algorithm when one search exceeds L ms (default 300)\n");
+    printf("\t-dif          also print the best and the worst time\n");
+    printf("\t-std          also print the standard deviation\n");
+    printf("\t-txt          write the result table as results/<code>/<corpus>.txt\n");
+    printf("\t-tex          write it as a LaTeX tabular too\n");
+    printf("\t-simple P T   one search of pattern P (<= 100 chars) in text T (<= 1000 chars)\n");
     printf("\t-algo LIST    comma separated algorithms out of hor,bm,kmp,so,bndm,epsm (default: all six,\n");
     printf("\t              or the ones marked #1 in source/algorithms.h when that file exists)\n");
     printf("\t-data DIR     directory holding <corpus>/index.txt (default \"data\")\n");
     printf("\t-gpu D        device ordinal (default 0)\n");
     printf("\t-gpus K       shard the text by byte offset over GPUs 0..K-1 (RCCL sum of the counts)\n");
-    printf("\t-h            gives this help list\n\n");
+    printf("\t-h            this help\n\n");
 }
 
 static int is_number(const char *s)
