@@ -365,13 +365,17 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
     constexpr int TB = THREADS * L;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, H = a.halo, H16 = round16(H);
-    uint16_t* bc = reinterpret_cast<uint16_t*>(smem);
+    // first[c] = shift after a mismatch on the window's LAST byte, max(gs[m-1], bc[c]), or
+    // 0x8000 when c == P[m-1]: like Horspool, a window that dies on its last byte (almost
+    // all of them on large alphabets) costs one text read and one table read
+    uint16_t* first = reinterpret_cast<uint16_t*>(smem);
+    uint16_t* bc = first + 256;
     uint16_t* gs = bc + 256;
-    uint8_t* ptail = smem + 512 + round16(2 * (m + 1));
+    uint8_t* ptail = smem + 1024 + round16(2 * (m + 1));
     uint8_t* txt = ptail + round16(H + 1);
 
     const uint16_t* gtab = reinterpret_cast<const uint16_t*>(a.blob + kTableOff);
-    for (uint32_t i = threadIdx.x; i < 256 + m + 1; i += THREADS) bc[i] = gtab[i];  // bc, gs[0..m-1], safe shift
+    for (uint32_t i = threadIdx.x; i < 512 + m + 1; i += THREADS) first[i] = gtab[i];  // first, bc, gs[0..m-1], safe shift
     for (uint32_t i = threadIdx.x; i <= H; i += THREADS) ptail[i] = a.blob[m - 1 - H + i];
 
     const uint64_t e_begin = a.s_begin + m - 1, e_end = a.s_end + m - 1;
@@ -413,7 +417,13 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
             const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
             while (e < ehi) {
                 // right-to-left comparison (bm.c:83); k = bytes matched
-                uint32_t k = 0, c = 0;
+                uint32_t c = txt[e];
+                const uint32_t ent = first[c];
+                if (!(ent & 0x8000u)) {  // mismatch on the last byte: bm.c:89 with i = m-1
+                    e += ent;
+                    continue;
+                }
+                uint32_t k = 1;
                 bool mismatch = false;
                 while (k <= H) {
                     c = txt[e - k];
@@ -472,8 +482,11 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
     uint32_t* B = reinterpret_cast<uint32_t*>(smem);
     uint8_t* txt = smem + 1024;
 
+    // masks left-aligned (B'[c] = B[c] << (32-w)): D <<= 1 then drops factors that can no
+    // longer become a prefix, instead of carrying dead bits above bit w-1 as bndm.c's 32-bit
+    // word does for m < 32 (they are cleared by the next AND either way: same D & B, same count)
     for (uint32_t i = threadIdx.x; i < 256; i += THREADS)
-        B[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i];
+        B[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] << (32 - w);
 
     const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
     uint32_t hits = 0;
@@ -513,30 +526,37 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
             uint32_t e = (uint32_t)(lo - tile0) + H16;
             const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
             while (e < ehi) {
-                int i = (int)w - 1;
-                uint32_t last = w, D = 0xFFFFFFFFu, k = 0;
-                while (i >= 0 && D != 0) {  // bndm.c:49-58
-                    D &= B[txt[e - k]];
-                    ++k;
-                    --i;
-                    if (D != 0) {
-                        if (i >= 0) {
-                            last = (uint32_t)i + 1;
-                        } else if (!LONG) {
-                            ++hits;
+                // bndm.c:49-58 with the first step peeled: D = ~0 & B[c], and B[c] == 0 (c does
+                // not occur in the prefix) moves the window by w after one text and one table read
+                uint32_t D = B[txt[e]];
+                if (D == 0) {
+                    e += w;
+                    continue;
+                }
+                int i = (int)w - 2;  // bytes still to read, minus one
+                uint32_t last = w, k = 1;
+                for (;;) {  // here D != 0 after k bytes
+                    if (i >= 0) {
+                        last = (uint32_t)i + 1;
+                    } else if (!LONG) {
+                        ++hits;
+                    } else {
+                        // prefix of 32 matched: verify P[32..m) (bndm.c:99-102),
+                        // the window is inside the text because s < s_end
+                        const uint8_t* rest = a.text + tile0 + (e - H16) + 1;  // = text + s + w
+                        if (!parked) {
+                            parked = true;
+                            parked_at = rest;
                         } else {
-                            // prefix of 32 matched: verify P[32..m) (bndm.c:99-102),
-                            // the window is inside the text because s < s_end
-                            const uint8_t* rest = a.text + tile0 + (e - H16) + 1;  // = text + s + w
-                            if (!parked) {
-                                parked = true;
-                                parked_at = rest;
-                            } else {
-                                hits += global_equal(rest, a.blob + w, m - w);
-                            }
+                            hits += global_equal(rest, a.blob + w, m - w);
                         }
                     }
                     D <<= 1;
+                    if (i < 0 || D == 0) break;
+                    D &= B[txt[e - k]];
+                    ++k;
+                    --i;
+                    if (D == 0) break;
                 }
                 e += last;
             }
@@ -1366,10 +1386,10 @@ hipError_t launch_tiled(K kernel, const ScanArgs& a, TileRange tr, int threads, 
 
 int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 // skip algorithms use the packed matcher up to this m (crossovers measured on 1 GiB rand128
-// with non-temporal tile loads, profiles/r01): HOR 7, BM 13, BNDM 11
+// with non-temporal tile loads, profiles/r01): HOR 7, BM 8, BNDM 11
 static constexpr uint32_t packed_max_m(int algo)
 {
-    return algo == SMARTGPU_HOR ? 7u : algo == SMARTGPU_BM ? 13u : algo == SMARTGPU_BNDM ? 11u : 0u;
+    return algo == SMARTGPU_HOR ? 7u : algo == SMARTGPU_BM ? 8u : algo == SMARTGPU_BNDM ? 11u : 0u;
 }
 
 // tile shapes (threads, bytes per lane)
@@ -1511,11 +1531,11 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
         case SMARTGPU_BM: {
             if ((m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
                 ScanArgs b = a;
-                b.fp_off = kTableOff + ((512 + 2 * (m + 1) + 3) & ~3u);  // after bc, gs, safe shift
+                b.fp_off = kTableOff + ((1024 + 2 * (m + 1) + 3) & ~3u);  // after first, bc, gs, safe shift
                 return launch_packed<SMARTGPU_BM>(b, num_cus, stream);
             }
             const uint32_t H = a.halo;
-            const size_t lds = 512 + r16(2 * (m + 1)) + r16(H + 1) + r16(H) + (size_t)kBmT * kBmL;
+            const size_t lds = 1024 + r16(2 * (m + 1)) + r16(H + 1) + r16(H) + (size_t)kBmT * kBmL;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmT * kBmL);
             const int wgs = g_tune[4] ? g_tune[4] : (lds <= 20 * 1024 ? 8 : 6);  // workgroups per CU by LDS footprint
             if (m - 1 > H) return launch_tiled(bm_scan<kBmT, kBmL, true>, a, tr, kBmT, lds, wgs, num_cus, stream);

@@ -37,7 +37,7 @@ struct ScanArgs {
 
 // Byte offsets of the tables inside the blob, after the pattern slot.
 //  HOR : u16 tab[256]   shift | 0x8000 if c == P[m-1]; u8 tab8[256]; fingerprint (as EPSM)
-//  BM  : u16 bc[256], u16 gs[m], u16 safe_shift
+//  BM  : u16 first[256] (last-byte shift | 0x8000 if c == P[m-1]), u16 bc[256], u16 gs[m], u16 safe_shift
 //  KMP : i16 next[m+1]; for m <= kKmpDfaMaxM also u8 dfa[(m+1)*256] (16-byte aligned)
 //  SO  : u32 S[256]
 //  BNDM: u32 B[256]
