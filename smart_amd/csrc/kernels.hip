@@ -996,23 +996,45 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
 // lane's run is 80 bytes and the w-1 bytes it re-scans to rebuild the state cost up
 // to 39 % extra work per owned byte (the kernel is VALU-bound: rocprofv3 shows 76 %
 // VALU busy); runs of 1 KiB make that 3 %.  Same recurrence as so_scan.
-template <bool LONG>
-__global__ __launch_bounds__(256) void so_runs(ScanArgs a, uint32_t run_len, uint64_t nruns)
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
+
+template <bool LONG, int WAVES, bool BP>  // BP: bank-private table (one copy of S' per lane)
+__global__ __launch_bounds__(WAVES * 64) void so_runs(ScanArgs a, uint32_t run_len, uint64_t nruns)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* S = reinterpret_cast<uint32_t*>(smem);  // 257 entries, padded to 1040 B
-    uint8_t* slab = smem + 1040 + wave * kRunSlab;
-    for (uint32_t i = threadIdx.x; i < 257; i += 256)
-        S[i] = (i < 256 ? reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] : 0xFFFFFFFFu) << (32 - w);
+    // BP = false: u32 S'[257], padded to 1040 B (S'[256] = sentinel).
+    // BP = true : u32 S'[256][64] — entry c of lane l at byte c*256 + l*4, i.e. always in bank l
+    // (ds_read_b32 banks are (a/4) mod 32 over two 32-lane groups): a gather of 64 different
+    // bytes is conflict-free by construction (shared table: 3x conflicts on rand128, measured),
+    // and the address is ONE v_perm_b32 (byte 1 = text byte, byte 0 = 4*lane).
+    constexpr uint32_t kTableBytes = BP ? 65536u : 1040u;
+    uint32_t* S = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* slab = smem + kTableBytes + wave * kRunSlab;
+    const uint32_t sentinel = 0xFFFFFFFFu << (32 - w);
+    if (BP) {
+        for (uint32_t i = threadIdx.x; i < 256 * 64; i += WAVES * 64)
+            S[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i >> 6] << (32 - w);
+    } else {
+        for (uint32_t i = threadIdx.x; i < 257; i += WAVES * 64)
+            S[i] = (i < 256 ? reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] : 0xFFFFFFFFu) << (32 - w);
+    }
+    // the perm result IS the LDS address: the table sits at LDS offset 0 (this kernel has no
+    // static LDS, so the dynamic segment starts there); checked below
+    const uint32_t lane4 = lane * 4u;
+    if (BP && (uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
+        return;
+    }
     __syncthreads();  // the only workgroup barrier: table visible
 
     uint32_t hits = 0;
     const uint64_t run_first = a.s_begin / run_len;
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint64_t nwaves = (uint64_t)gridDim.x * WAVES;
     const uint32_t nsteps = (run_len + w - 1 + 63) / 64;
-    for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g * 64 < nruns; g += nwaves) {
+    for (uint64_t g = (uint64_t)blockIdx.x * WAVES + wave; g * 64 < nruns; g += nwaves) {
         const uint8_t* src[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1028,14 +1050,26 @@ __global__ __launch_bounds__(256) void so_runs(ScanArgs a, uint32_t run_len, uin
         const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
         const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
 
-        uint4 nx0 = *reinterpret_cast<const uint4*>(src[0]);
-        uint4 nx1 = *reinterpret_cast<const uint4*>(src[1]);
-        uint4 nx2 = *reinterpret_cast<const uint4*>(src[2]);
-        uint4 nx3 = *reinterpret_cast<const uint4*>(src[3]);
+        // two steps (2 x 64 B per run, 8 KB per wave) are in flight in registers: one step per
+        // wave left the kernel latency-bound (bytes in flight per CU = rate x HBM latency, PMC)
+        uint4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
+        auto fetch = [&](uint32_t k, uint4& r0, uint4& r1, uint4& r2, uint4& r3) {
+            // unconditional (past the last step: the last step again, a cache hit), so that the
+            // number of loads in flight is static and the waits are vmcnt(4), not vmcnt(0)
+            const uint32_t o = (k < nsteps ? k : nsteps - 1) * 64u;
+            r0 = *reinterpret_cast<const uint4*>(src[0] + o);
+            r1 = *reinterpret_cast<const uint4*>(src[1] + o);
+            r2 = *reinterpret_cast<const uint4*>(src[2] + o);
+            r3 = *reinterpret_cast<const uint4*>(src[3] + o);
+        };
+        fetch(0, pa0, pa1, pa2, pa3);
+        __builtin_amdgcn_sched_barrier(0);  // keep the issue order: the loop waits with vmcnt(4)
+        fetch(1, pb0, pb1, pb2, pb3);
+        __builtin_amdgcn_sched_barrier(0);
         uint32_t D = 0xFFFFFFFFu << (32 - w);
         bool parked = false;
         const uint8_t* parked_at = a.text;
-        for (uint32_t k = 0; k < nsteps; ++k) {
+        auto step = [&](uint32_t k, uint4& nx0, uint4& nx1, uint4& nx2, uint4& nx3) {
             {
                 uint8_t* dst = slab + (lane >> 2) * 80u + (lane & 3u) * 16u;
                 *reinterpret_cast<uint4*>(dst) = nx0;
@@ -1043,14 +1077,62 @@ __global__ __launch_bounds__(256) void so_runs(ScanArgs a, uint32_t run_len, uin
                 *reinterpret_cast<uint4*>(dst + 32 * 80) = nx2;
                 *reinterpret_cast<uint4*>(dst + 48 * 80) = nx3;
             }
-            if (k + 1 < nsteps) {
-                const uint32_t o = (k + 1) * 64u;
-                nx0 = *reinterpret_cast<const uint4*>(src[0] + o);
-                nx1 = *reinterpret_cast<const uint4*>(src[1] + o);
-                nx2 = *reinterpret_cast<const uint4*>(src[2] + o);
-                nx3 = *reinterpret_cast<const uint4*>(src[3] + o);
-            }
+            fetch(k + 2, nx0, nx1, nx2, nx3);
             const uint8_t* mine = slab + lane * 80u;
+            // hit mask of one 16-byte chunk (bit 15-q: a window ends at byte q)
+            auto take_hits = [&](uint32_t base, uint32_t hm) {
+                if (!LONG) {
+                    hits += __popc(hm);
+                } else {
+                    while (hm) {  // 32-byte prefix matched, ending at byte q: verify P[32..m)
+                        const uint32_t bit = 31u - __builtin_clz(hm);
+                        hm &= ~(1u << bit);
+                        const uint8_t* rest = a.text + seg + base + (15u - bit) + 1;
+                        if (!parked) {
+                            parked = true;
+                            parked_at = rest;
+                        } else {
+                            hits += global_equal(rest, a.blob + w, m - w);
+                        }
+                    }
+                }
+            };
+            if (BP && k * 64u >= j0 && k * 64u + 64u <= jend) {
+                // the whole 64-byte step is inside the run (all steps but a run's first/last):
+                // straight-line code, so the 64 gathers are in flight under the recurrence
+                // (the long-pattern instantiation gathers 32 bytes at a time: its verify path
+                // needs the registers)
+                constexpr int NB = LONG ? 2 : 1;   // gather batches per step
+                constexpr int CB = 4 / NB;         // 16-byte chunks per batch
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    uint32_t sv[16 * CB];
+#pragma unroll
+                    for (int c4 = 0; c4 < CB; ++c4) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(mine + 16 * (CB * nb + c4));
+                        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            sv[16 * c4 + q] = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
+                    }
+#pragma unroll
+                    for (int h = 0; h < CB / 2; ++h) {
+                        uint32_t H = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int q = 0; q < 32; ++q) {
+                            D = (D << 1) | sv[32 * h + q];            // so.c:55
+                            H = __builtin_amdgcn_alignbit(H, D, 31);  // so.c:56: sign bit clear <=> hit
+                        }
+                        const uint32_t base = k * 64u + 16u * CB * nb + 32u * h;
+                        if (!LONG) {
+                            hits += __popc(~H);
+                        } else {
+                            take_hits(base, ~H >> 16);
+                            take_hits(base + 16u, ~H & 0xFFFFu);
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 const uint32_t base = k * 64u + 16u * c4;
@@ -1059,7 +1141,18 @@ __global__ __launch_bounds__(256) void so_runs(ScanArgs a, uint32_t run_len, uin
                 const uint32_t d[4] = {v.x, v.y, v.z, v.w};
                 const bool full = base >= j0 && base + 16 <= jend;
                 uint32_t sv[16];
-                if (full) {
+                if (BP) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        sv[q] = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
+                    if (!full) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const uint32_t j = base + q;
+                            sv[q] = (j >= j0 && j < jend) ? sv[q] : sentinel;
+                        }
+                    }
+                } else if (full) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) sv[q] = S[(d[q >> 2] >> (8 * (q & 3))) & 0xFFu];
                 } else {
@@ -1076,27 +1169,17 @@ __global__ __launch_bounds__(256) void so_runs(ScanArgs a, uint32_t run_len, uin
                     D = (D << 1) | sv[q];                     // so.c:55
                     H = __builtin_amdgcn_alignbit(H, D, 31);  // so.c:56: sign bit clear <=> hit
                 }
-                uint32_t hm = ~H & 0xFFFFu;
-                if (!LONG) {
-                    hits += __popc(hm);
-                } else {
-                    while (hm) {  // 32-byte prefix matched, ending at byte q: verify P[32..m)
-                        const uint32_t bit = 31u - __builtin_clz(hm);
-                        hm &= ~(1u << bit);
-                        const uint8_t* rest = a.text + seg + base + (15u - bit) + 1;
-                        if (!parked) {
-                            parked = true;
-                            parked_at = rest;
-                        } else {
-                            hits += global_equal(rest, a.blob + w, m - w);
-                        }
-                    }
-                }
+                take_hits(base, ~H & 0xFFFFu);
+            }
             }
             if (LONG && __any(parked)) {  // keep at most one parked window per lane
                 hits += wave_verify(parked, parked_at, a.blob + w, m - w);
                 parked = false;
             }
+        };
+        for (uint32_t k = 0; k < nsteps; k += 2) {  // an odd nsteps runs one empty step (k*64 >= jend)
+            step(k, pa0, pa1, pa2, pa3);
+            step(k + 1, pb0, pb1, pb2, pb3);
         }
     }
     flush_hits(hits, a.count);
@@ -1555,7 +1638,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
         }
         case SMARTGPU_SO: {
             if (g_tune[6] != 1) {  // per-lane runs through LDS slabs (tune[6]=1: LDS tiles, for A/B)
-                uint64_t L = g_tune[5] ? (uint64_t)g_tune[5] : 1024;
+                uint64_t L = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
                 const uint64_t fill = (a.s_end - a.s_begin) / ((uint64_t)num_cus * 16 * 64);
                 if (L > fill) L = fill;
                 if (L < 256) L = 256;
@@ -1565,11 +1648,25 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 uint64_t grid = ((uint64_t)tr.count + 255) / 256;
                 const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 6);
                 if (grid > cap) grid = cap;
-                const size_t lds = 1040 + 4 * (size_t)kRunSlab;
+                if (g_tune[6] == 2) {  // shared table, 256-thread workgroups (A/B)
+                    const size_t lds = 1040 + 4 * (size_t)kRunSlab;
+                    if (m > 32)
+                        hipLaunchKernelGGL((so_runs<true, 4, false>), dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                    else
+                        hipLaunchKernelGGL((so_runs<false, 4, false>), dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                    return hipGetLastError();
+                }
+                // bank-private table: 64 KB shared by the 16 waves of ONE workgroup per CU
+                const size_t lds = 65536 + 16 * (size_t)kRunSlab;
+                grid = ((uint64_t)tr.count + 1023) / 1024;
+                if (grid > (uint64_t)num_cus) grid = num_cus;
+                const void* fn = m > 32 ? reinterpret_cast<const void*>(so_runs<true, 16, true>)
+                                        : reinterpret_cast<const void*>(so_runs<false, 16, true>);
+                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (m > 32)
-                    hipLaunchKernelGGL(so_runs<true>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                    hipLaunchKernelGGL((so_runs<true, 16, true>), dim3((uint32_t)grid), dim3(1024), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
                 else
-                    hipLaunchKernelGGL(so_runs<false>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                    hipLaunchKernelGGL((so_runs<false, 16, true>), dim3((uint32_t)grid), dim3(1024), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
                 return hipGetLastError();
             }
             const size_t lds = 1040 + (size_t)kSoT * kSoL + 32;
