@@ -228,19 +228,15 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             for (uint32_t i = 0; i <= m; ++i) tab[i] = static_cast<int16_t>(nx[i]);
             append(tab.data(), tab.size() * 2);
             *halo = m - 1;  // forward halo: the automaton re-scans m-1 bytes
-            if (m <= sg::kKmpDfaMaxM) {  // transition table for kmp_runs<true>, 16-byte aligned
+            {   // transition table of the automaton for P[0..w), 16-byte aligned (kmp_runs)
+                const uint32_t w = std::min<uint32_t>(m, sg::kKmpDfaMaxM);
                 blob.resize((blob.size() + 15) & ~size_t(15), 0);
-                const std::vector<uint8_t> dfa = sg::kmp_dfa(P, m);
-                append(dfa.data(), dfa.size());
-            } else {  // table over the pattern's own alphabet; for m > 255: of its 255-byte prefix
-                uint32_t k1 = 0;
-                const uint32_t w = std::min<uint32_t>(m, sg::kKmpDfaCompMaxM);
-                const std::vector<uint8_t> dfa = sg::kmp_dfa_compressed(P, w, &k1);
-                if (dfa.size() - 256 <= sg::kKmpDfaCompMaxBytes) {
-                    blob.resize((blob.size() + 15) & ~size_t(15), 0);
-                    append(dfa.data(), dfa.size());
-                    *kmp_k1 = k1;
-                }
+                const std::vector<uint8_t> dfa = sg::kmp_dfa(P, w);
+                // row s is stored XOR-swizzled by s (kmp_delta in kernels.hip: LDS bank spread)
+                std::vector<uint8_t> sw(dfa.size());
+                for (uint32_t st = 0; st <= w; ++st)
+                    for (uint32_t c = 0; c < 256; ++c) sw[st * 256 + (c ^ st)] = dfa[st * 256 + c];
+                append(sw.data(), sw.size());
             }
             break;
         }

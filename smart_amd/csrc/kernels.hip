@@ -718,6 +718,10 @@ __device__ __forceinline__ void kmp_chunk(const uint4& v, uint32_t j_base, uint3
         }
         const bool slow = live && st != 0;
         int st_new = (c == p0) ? 1 : 0;  // from state 0: next[0] = -1, then ++ (kmp.c:57-60)
+        if (m == 1 && live && st_new) {  // a one-byte pattern is complete here (kmp.c:61-64)
+            ++hits;
+            st_new = next_m;
+        }
         if (__any(slow)) {
             if (slow) {
                 int s2 = st;
@@ -797,10 +801,9 @@ __global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a, uint64_t tile_fi
     flush_hits(hits, a.count);
 }
 
-// KMP over per-lane RUNS streamed through LDS (m > 40, and every m <= 95 via the
-// transition table).  A lane owns a run of `run_len` start positions (any length:
-// the host picks it from m so that the re-scan of m-1 bytes is bounded), but a
-// lane-private stream is a terrible access pattern (64 lanes x 16 B from 64
+// KMP over per-lane RUNS streamed through LDS.  A lane owns a run of `run_len` start
+// positions (any length: the host picks it from m so that the re-scan of m-1 bytes is
+// bounded), but a lane-private stream is a terrible access pattern (64 lanes x 16 B from 64
 // different lines per wave-load: 1.1 TB/s measured even with no automaton work).
 // So the WAVE moves the data: per step it fetches the next 64 bytes of each of its
 // 64 runs with four coalesced wave-loads (4 lanes cover one run's 64-byte sector),
@@ -809,95 +812,225 @@ __global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a, uint64_t tile_fi
 // bytes back.  No workgroup barrier: a wave's DS operations execute in order.
 // The next step's loads are issued before the current step is processed.
 //
-// DFA = true (m <= 95): the failure function is expanded on the host into the
-// automaton's transition table delta[s][c] (u8, (m+1)*256 B in LDS), so a text byte
-// costs ONE dependent LDS lookup, no data-dependent loop: st = delta[st][c].
-// DFA = false: failure links (kmp_chunk above).
+// kmp_runs: the failure function (kmp.c:27-41) is expanded on the host into the automaton's
+// transition table delta[s][c] (u8, 256 columns, (w+1)*256 B at LDS offset 0, w = min(m,255)),
+// so a text byte costs ONE dependent LDS lookup and no data-dependent loop: st = delta[st][c].
+// The address st*256 + c is ONE v_perm_b32 (byte 1 = state, byte 0 = text byte).  The accept
+// state w is the largest state id, so "did an occurrence end in these 64 bytes" is a running
+// maximum (v_max3_u32: half an op per byte); only a lane that saw one walks its 64 bytes again,
+// counting.  One 1024-thread workgroup per CU shares the table (64 KB at m >= 255).
+// kmp_links_runs: the failure links themselves (kmp_chunk above), for A/B.
 constexpr int kRunSlab = 64 * 80;  // LDS bytes per wave
 
-template <bool CHECK>
-__device__ __forceinline__ void kmp_dfa_chunk(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
-                                              uint32_t& st, uint32_t& hits, uint32_t m,
-                                              const uint8_t* __restrict__ dfa)
-{
-    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
-        const uint32_t nx = dfa[(st << 8) | c];
-        if (CHECK) {
-            const uint32_t j = j_base + q;
-            const bool live = j >= j0 && j < jend;
-            st = live ? nx : st;
-            hits += live && nx == m;
-        } else {
-            st = nx;
-            hits += nx == m;
-        }
-    }
-}
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
 
-// Compressed table: the 16 column lookups colmap[c] do not depend on the state and are
-// issued together; the state chain then costs one dependent lookup per byte as above.
 // MASK: instead of counting, return the chunk's hits as a bit mask in `hits` (bit q = the
-// automaton reached state m at byte q) — the long-pattern mode, where a hit is only a
+// automaton reached state w at byte q) — the long-pattern mode, where a hit is only a
 // 255-byte prefix match that still has to be verified.
-template <bool CHECK, bool MASK = false>
-__device__ __forceinline__ void kmp_dfac_chunk(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
-                                               uint32_t& st, uint32_t& hits, uint32_t m, uint32_t k1,
-                                               const uint8_t* __restrict__ colmap,
-                                               const uint8_t* __restrict__ table)
+// delta[st][c]: one v_perm_b32 builds st*256 + c; the row of state st is stored XOR-swizzled,
+// delta[st][c] at st*256 + (c ^ st), which costs one v_xor: every row starts on LDS bank 0, so on
+// a small alphabet (few distinct c) lanes in different states would all meet on the same few
+// banks (rand2: 33 % -> 42-48 % of 8 TB/s with the swizzle, rand128 unchanged).
+__device__ __forceinline__ uint32_t kmp_delta(uint32_t dword, uint32_t st, int byte)
+{
+    const uint32_t addr = __builtin_amdgcn_perm(dword, st, 0x0c0c0004u + byte) ^ st;
+    return *(const lds_u8_t*)(size_t)addr;
+}
+
+template <bool CHECK, bool MASK>
+__device__ __forceinline__ void kmp_dfa_chunk(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
+                                              uint32_t& st, uint32_t& hits, uint32_t w)
 {
     const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-    uint32_t col[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) col[q] = colmap[(d[q >> 2] >> (8 * (q & 3))) & 0xFFu];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const uint32_t nx = table[st * k1 + col[q]];
+        const uint32_t nx = kmp_delta(d[q >> 2], st, q & 3);
         if (CHECK) {
             const uint32_t j = j_base + q;
             const bool live = j >= j0 && j < jend;
             st = live ? nx : st;
-            if (MASK) hits |= (live && nx == m) ? (1u << q) : 0u;
-            else hits += live && nx == m;
+            if (MASK) hits |= (live && nx == w) ? (1u << q) : 0u;
+            else hits += live && nx == w;
         } else {
             st = nx;
-            if (MASK) hits |= (nx == m) ? (1u << q) : 0u;
-            else hits += nx == m;
+            if (MASK) hits |= (nx == w) ? (1u << q) : 0u;
+            else hits += nx == w;
         }
     }
 }
 
-// DFA: 0 failure links, 1 full 256-column table (m <= 64), 2 table over the pattern's own
-// alphabet (m <= 255), 3 the same table for the 255-byte PREFIX of a longer pattern: a
-// prefix hit is verified in memory (parked for wave_verify), as so.c / bndm.c do with their
-// 32-byte prefix for m > 32.  Every occurrence of P starts with an occurrence of its prefix.
-template <int DFA>
-__global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
-                                                uint32_t dfa_off)
+// The common case: 16 transitions, running maximum of the states (no hit bookkeeping).
+__device__ __forceinline__ void kmp_dfa_chunk_max(const uint4& v, uint32_t& st, uint32_t& mx)
+{
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+        const uint32_t s1 = kmp_delta(d[q >> 2], st, q & 3);
+        const uint32_t s2 = kmp_delta(d[q >> 2], s1, (q + 1) & 3);
+        st = s2;
+        mx = max(max(mx, s1), s2);
+    }
+}
+
+template <bool PREFIX>  // PREFIX: m > 255 — the automaton of the 255-byte prefix; hits are verified
+__global__ __launch_bounds__(1024) void kmp_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
+                                                 uint32_t dfa_off)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t kWaves = 16;
+    const uint32_t m = a.m;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t w = PREFIX ? kKmpDfaMaxM : m;  // length the automaton recognises = accept state
+    const uint32_t table_bytes = (w + 1) * 256;
+    uint8_t* slab = smem + table_bytes + wave * kRunSlab;
+    {
+        const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
+        uint4* t = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = threadIdx.x; i < table_bytes / 16; i += kWaves * 64) t[i] = g[i];
+    }
+    // the perm result IS the LDS address: the table sits at LDS offset 0 (no static LDS in
+    // this kernel, so the dynamic segment starts there); a poisoned count if that ever changes
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
+        return;
+    }
+    __syncthreads();  // the only workgroup barrier: table visible
+
+    uint32_t hits = 0;
+    const uint64_t run_first = a.s_begin / run_len;  // runs are cut on absolute offsets
+    const uint64_t nwaves = (uint64_t)gridDim.x * kWaves;
+    const uint32_t span = run_len + w - 1;           // bytes a run scans
+    const uint32_t nsteps = (span + 63) / 64;
+    // group = 64 consecutive runs handled by one wave
+    for (uint64_t g = (uint64_t)blockIdx.x * kWaves + wave; g * 64 < nruns; g += nwaves) {
+        // loader role: lane covers piece (lane & 3) of runs 16*i + (lane >> 2), i = 0..3
+        const uint8_t* src[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint64_t r = g * 64 + 16 * i + (lane >> 2);
+            if (r >= nruns) r = nruns - 1;  // clamp: loaded but never consumed
+            src[i] = a.text + (run_first + r) * run_len + (lane & 3u) * 16u;
+        }
+        // owner role: this lane's run and the bytes of it that count
+        const uint64_t my = g * 64 + lane;
+        const uint64_t seg = (run_first + my) * run_len;
+        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
+        const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
+        const bool owner = my < nruns && sa < sb;
+        const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
+        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
+
+        uint4 nx0 = *reinterpret_cast<const uint4*>(src[0]);
+        uint4 nx1 = *reinterpret_cast<const uint4*>(src[1]);
+        uint4 nx2 = *reinterpret_cast<const uint4*>(src[2]);
+        uint4 nx3 = *reinterpret_cast<const uint4*>(src[3]);
+        uint32_t st = 0;
+        bool dense = false;   // wave-uniform: the last whole step reached the accept state
+        bool parked = false;  // PREFIX: first unverified prefix hit of this step
+        const uint8_t* parked_at = a.text;
+        for (uint32_t k = 0; k < nsteps; ++k) {
+            // park this step's 64 bytes of every run in the slab
+            {
+                uint8_t* dst = slab + (lane >> 2) * 80u + (lane & 3u) * 16u;
+                *reinterpret_cast<uint4*>(dst) = nx0;
+                *reinterpret_cast<uint4*>(dst + 16 * 80) = nx1;
+                *reinterpret_cast<uint4*>(dst + 32 * 80) = nx2;
+                *reinterpret_cast<uint4*>(dst + 48 * 80) = nx3;
+            }
+            if (k + 1 < nsteps) {  // prefetch the next step (wave-uniform)
+                const uint32_t o = (k + 1) * 64u;
+                nx0 = *reinterpret_cast<const uint4*>(src[0] + o);
+                nx1 = *reinterpret_cast<const uint4*>(src[1] + o);
+                nx2 = *reinterpret_cast<const uint4*>(src[2] + o);
+                nx3 = *reinterpret_cast<const uint4*>(src[3] + o);
+            }
+            const uint32_t jb = k * 64u;
+            const uint8_t* mine = slab + lane * 80u;
+            // one 16-byte chunk with hit bookkeeping (run boundaries, and steps that reach state w);
+            // returns whether the accept state was seen
+            auto careful = [&](int q, bool whole) -> bool {
+                const uint4 v = *reinterpret_cast<const uint4*>(mine + 16 * q);
+                const uint32_t j = jb + 16u * q;
+                if (!PREFIX) {
+                    const uint32_t h0 = hits;
+                    if (whole) kmp_dfa_chunk<false, false>(v, j, j0, jend, st, hits, w);
+                    else if (j < jend && j + 16 > j0) kmp_dfa_chunk<true, false>(v, j, j0, jend, st, hits, w);
+                    return hits != h0;
+                } else {
+                    uint32_t hm = 0;
+                    if (whole) kmp_dfa_chunk<false, true>(v, j, j0, jend, st, hm, w);
+                    else if (j < jend && j + 16 > j0) kmp_dfa_chunk<true, true>(v, j, j0, jend, st, hm, w);
+                    const bool seen = hm != 0;
+                    while (hm) {  // the prefix ends at byte j+b: verify P[255..m)
+                        const uint32_t b = __builtin_ctz(hm);
+                        hm &= hm - 1;
+                        const uint8_t* rest = a.text + seg + j + b + 1;  // = text + start + w
+                        if (!parked) {
+                            parked = true;
+                            parked_at = rest;
+                        } else {
+                            hits += global_equal(rest, a.blob + w, m - w);
+                        }
+                    }
+                    return seen;
+                }
+            };
+            if (jb >= j0 && jb + 64u <= jend) {  // the whole step is inside the run
+                bool seen = false;
+                if (!dense) {
+                    const uint32_t st0 = st;
+                    uint32_t mx = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        kmp_dfa_chunk_max(*reinterpret_cast<const uint4*>(mine + 16 * q), st, mx);
+                    seen = mx == w;
+                    if (seen) {  // the accept state was reached: walk the step again, counting
+                        st = st0;
+#pragma unroll 1
+                        for (int q = 0; q < 4; ++q) careful(q, true);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int q = 0; q < 4; ++q) seen |= careful(q, true);
+                }
+                // where occurrences are frequent (short patterns, small alphabets) walking twice
+                // costs more than it saves: the wave counts directly while its last step saw any
+                dense = __any(seen);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t j = jb + 16u * q;
+                    careful(q, j >= j0 && j + 16 <= jend);
+                }
+            }
+            if (PREFIX && __any(parked)) {  // wave-uniform point: at most one parked hit per lane
+                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
+                parked = false;
+            }
+        }
+    }
+    flush_hits(hits, a.count);
+}
+
+// The failure links followed per byte (the reference's loop, kmp.c:55-66), A/B only: smartgpu_tune(3,2).
+__global__ __launch_bounds__(256) void kmp_links_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
+                                                uint32_t)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // LDS: [table][4 wave slabs]
-    const uint32_t k1 = a.kmp_k1;
-    const uint32_t w = DFA == 3 ? kKmpDfaCompMaxM : m;  // length the automaton recognises
-    const uint32_t table_bytes = DFA == 1 ? round16((m + 1) * 256)
-                               : DFA >= 2 ? round16(256 + (w + 1) * k1) : round16(4 * m);
+    const uint32_t w = m;
+    const uint32_t table_bytes = round16(4 * m);
     uint8_t* slab = smem + table_bytes + wave * kRunSlab;
     const int16_t* gnext = reinterpret_cast<const int16_t*>(a.blob + kTableOff);
-    if (DFA != 0) {
-        const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
-        uint4* t = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = threadIdx.x; i < table_bytes / 16; i += 256) t[i] = g[i];
-    } else {
+    {
         uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
         for (uint32_t i = threadIdx.x; i < m; i += 256)
             tab[i] = ((uint32_t)a.blob[i] << 16) | (uint16_t)gnext[i];
     }
     __syncthreads();  // the only workgroup barrier: tables visible
-    const uint8_t* dfa = smem;
     const uint32_t* tab = reinterpret_cast<const uint32_t*>(smem);
     const uint32_t p0 = a.blob[0];
     const int next_m = gnext[m];
@@ -930,10 +1063,7 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
         uint4 nx1 = *reinterpret_cast<const uint4*>(src[1]);
         uint4 nx2 = *reinterpret_cast<const uint4*>(src[2]);
         uint4 nx3 = *reinterpret_cast<const uint4*>(src[3]);
-        uint32_t st = 0;
         int sti = 0;
-        bool parked = false;  // DFA 3: first unverified prefix hit of this step
-        const uint8_t* parked_at = a.text;
         for (uint32_t k = 0; k < nsteps; ++k) {
             // park this step's 64 bytes of every run in the slab
             {
@@ -957,35 +1087,10 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
                 const uint4 v = *reinterpret_cast<const uint4*>(mine + 16 * q);
                 const uint32_t j = jb + 16u * q;
                 const bool full = j >= j0 && j + 16 <= jend;
-                if (DFA == 1) {
-                    if (full) kmp_dfa_chunk<false>(v, j, j0, jend, st, hits, m, dfa);
-                    else if (j < jend && j + 16 > j0) kmp_dfa_chunk<true>(v, j, j0, jend, st, hits, m, dfa);
-                } else if (DFA == 2) {
-                    if (full) kmp_dfac_chunk<false>(v, j, j0, jend, st, hits, m, k1, dfa, dfa + 256);
-                    else if (j < jend && j + 16 > j0) kmp_dfac_chunk<true>(v, j, j0, jend, st, hits, m, k1, dfa, dfa + 256);
-                } else if (DFA == 3) {
-                    uint32_t hm = 0;
-                    if (full) kmp_dfac_chunk<false, true>(v, j, j0, jend, st, hm, w, k1, dfa, dfa + 256);
-                    else if (j < jend && j + 16 > j0) kmp_dfac_chunk<true, true>(v, j, j0, jend, st, hm, w, k1, dfa, dfa + 256);
-                    while (hm) {  // the prefix ends at byte j+b: verify P[255..m)
-                        const uint32_t b = __builtin_ctz(hm);
-                        hm &= hm - 1;
-                        const uint8_t* rest = a.text + seg + j + b + 1;  // = text + start + w
-                        if (!parked) {
-                            parked = true;
-                            parked_at = rest;
-                        } else {
-                            hits += global_equal(rest, a.blob + w, m - w);
-                        }
-                    }
-                } else {
+                {
                     if (full) kmp_chunk<false>(v, j, j0, jend, sti, hits, (int)m, p0, next_m, tab);
                     else if (j < jend && j + 16 > j0) kmp_chunk<true>(v, j, j0, jend, sti, hits, (int)m, p0, next_m, tab);
                 }
-            }
-            if (DFA == 3 && __any(parked)) {  // wave-uniform point: at most one parked hit per lane
-                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
-                parked = false;
             }
         }
     }
@@ -996,9 +1101,6 @@ __global__ __launch_bounds__(256) void kmp_runs(ScanArgs a, uint32_t run_len, ui
 // lane's run is 80 bytes and the w-1 bytes it re-scans to rebuild the state cost up
 // to 39 % extra work per owned byte (the kernel is VALU-bound: rocprofv3 shows 76 %
 // VALU busy); runs of 1 KiB make that 3 %.  Same recurrence as so_scan.
-typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
-
 template <bool LONG, int WAVES, bool BP>  // BP: bank-private table (one copy of S' per lane)
 __global__ __launch_bounds__(WAVES * 64) void so_runs(ScanArgs a, uint32_t run_len, uint64_t nruns)
 {
@@ -1493,7 +1595,7 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
             return r == 3 ? "packed_scan" : r == 2 ? "hor_scan_bp" : "hor_scan";
         }
         case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
-        case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : "kmp_runs";
+        case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : "kmp_runs";
         case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : "so_runs";
         case SMARTGPU_BNDM: return (pk || (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1)) ? "packed_scan" : "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
@@ -1506,39 +1608,40 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
 static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream)
 {
     const uint32_t m = a.m;
-    const int dfa = m <= kKmpDfaMaxM ? 1 : !a.kmp_k1 ? 0 : m <= kKmpDfaCompMaxM ? 2 : 3;
-    const uint32_t w = dfa == 3 ? kKmpDfaCompMaxM : m;  // bytes re-scanned per run: w-1
+    const bool links = g_tune[3] == 2;                       // failure links, A/B
+    const uint32_t w = (links || m <= kKmpDfaMaxM) ? m : kKmpDfaMaxM;  // bytes re-scanned per run: w-1
     const uint64_t span = a.s_end - a.s_begin;
     uint64_t L = 8ull * (w - 1);
     const uint64_t fill = span / ((uint64_t)num_cus * 16 * 64);
     if (L > fill) L = fill;
     if (L < 2ull * (w - 1)) L = 2ull * (w - 1);
-    const uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 512;  // longer runs amortise the per-run set-up
+    const uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;  // longer runs amortise the per-run set-up
     if (L < lmin) L = lmin;
     L = (L + 63) & ~63ull;
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
-    const size_t table = dfa == 1 ? r16((m + 1) * 256) : dfa >= 2 ? r16(256 + (w + 1) * a.kmp_k1) : r16(4 * m);
-    const size_t lds = table + 4 * (size_t)kRunSlab;
-    uint64_t grid = ((uint64_t)tr.count + 255) / 256;
-    const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 4);
-    if (grid > cap) grid = cap;
     const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));
-    if (lds > 64 * 1024) {  // large own-alphabet tables need the opt-in for > 64 KiB of dynamic LDS
-        const void* fn = dfa == 2 ? reinterpret_cast<const void*>(kmp_runs<2>) : reinterpret_cast<const void*>(kmp_runs<3>);
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (links) {
+        const size_t lds = r16(4 * m) + 4 * (size_t)kRunSlab;
+        uint64_t grid = ((uint64_t)tr.count + 255) / 256;
+        const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 4);
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL(kmp_links_runs, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
+                           (uint64_t)tr.count, dfa_off);
+        return hipGetLastError();
     }
-    if (dfa == 1)
-        hipLaunchKernelGGL(kmp_runs<1>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
-                           (uint64_t)tr.count, dfa_off);
-    else if (dfa == 2)
-        hipLaunchKernelGGL(kmp_runs<2>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
-                           (uint64_t)tr.count, dfa_off);
-    else if (dfa == 3)
-        hipLaunchKernelGGL(kmp_runs<3>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
+    // one 1024-thread workgroup per CU: the table (up to 64 KB) is shared by 16 waves
+    const size_t lds = (size_t)(w + 1) * 256 + 16 * (size_t)kRunSlab;
+    uint64_t grid = ((uint64_t)tr.count + 1023) / 1024;
+    if (grid > (uint64_t)num_cus) grid = num_cus;
+    const void* fn = m > kKmpDfaMaxM ? reinterpret_cast<const void*>(kmp_runs<true>)
+                                     : reinterpret_cast<const void*>(kmp_runs<false>);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (m > kKmpDfaMaxM)
+        hipLaunchKernelGGL(kmp_runs<true>, dim3((uint32_t)grid), dim3(1024), lds, stream, a, (uint32_t)L,
                            (uint64_t)tr.count, dfa_off);
     else
-        hipLaunchKernelGGL(kmp_runs<0>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
+        hipLaunchKernelGGL(kmp_runs<false>, dim3((uint32_t)grid), dim3(1024), lds, stream, a, (uint32_t)L,
                            (uint64_t)tr.count, dfa_off);
     return hipGetLastError();
 }

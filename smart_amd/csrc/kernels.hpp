@@ -18,9 +18,9 @@ constexpr uint64_t kBackPad = 160 * 1024;       // >= largest tile + kXSize + 64
 constexpr uint32_t kHaloMax = 16;               // bytes a lane verifies by itself in LDS before it parks the window
 constexpr uint32_t kPatternBytes = 4224;        // pattern slot in the plan blob (>= kXSize, /16)
 constexpr int kResultSlots = 4096;
-constexpr uint32_t kKmpDfaMaxM = 64;            // KMP: (m+1)*256-byte transition table kept in LDS up to this m
-constexpr uint32_t kKmpDfaCompMaxM = 255;       // ... and a table over the pattern's own alphabet up to this m,
-constexpr uint32_t kKmpDfaCompMaxBytes = 57344; //     if it fits this many bytes (u8 states)
+constexpr uint32_t kKmpDfaMaxM = 255;  // KMP: the automaton's states are u8, so its (w+1)*256-byte transition
+                                       // table (<= 64 KB of LDS) recognises w = min(m, 255) bytes; longer
+                                       // patterns: the automaton of the 255-byte prefix + verification
 
 // What every scan kernel receives.
 struct ScanArgs {
@@ -30,7 +30,7 @@ struct ScanArgs {
     uint32_t halo;              // skip kernels: back-halo H = min(m-1, kHaloMax); serial: forward halo
     uint32_t fp_off;            // packed kernel: blob offset of the fingerprint (set by launch_scan)
     uint32_t prefer_packed;     // HOR/BM: the shift tables promise tiny shifts (small alphabet) -> packed regime
-    uint32_t kmp_k1;            // KMP: row stride of the compressed transition table, 0 if the blob has none
+    uint32_t kmp_k1;            // unused (was: row stride of a compressed KMP table)
     const uint8_t* blob;        // device: [pattern kPatternBytes][tables ...]
     unsigned long long* count;  // device result slot (pre-zeroed)
 };
@@ -38,7 +38,8 @@ struct ScanArgs {
 // Byte offsets of the tables inside the blob, after the pattern slot.
 //  HOR : u16 tab[256]   shift | 0x8000 if c == P[m-1]; u8 tab8[256]; fingerprint (as EPSM)
 //  BM  : u16 first[256] (last-byte shift | 0x8000 if c == P[m-1]), u16 bc[256], u16 gs[m], u16 safe_shift
-//  KMP : i16 next[m+1]; for m <= kKmpDfaMaxM also u8 dfa[(m+1)*256] (16-byte aligned)
+//  KMP : i16 next[m+1]; u8 dfa[(w+1)*256], w = min(m, kKmpDfaMaxM), 16-byte aligned, row s XOR-swizzled:
+//        delta(s,c) at s*256 + (c ^ s)
 //  SO  : u32 S[256]
 //  BNDM: u32 B[256]
 //  EPSM: u32 fp[4], u32 fpmask[4]   (first min(m,16) pattern bytes as dwords + byte masks)

@@ -110,12 +110,14 @@ def test_packed_load_policies(oracle, policy):
         engine.tune(7, 0)
 
 
-def test_alternate_serial_kernels(oracle):
-    """SO and KMP normally run on the runs-through-LDS kernels; the LDS-tile variants
-    (kept for A/B measurements) must give the same counts."""
+@pytest.mark.parametrize("variant", [1, 2])
+def test_alternate_serial_kernels(oracle, variant):
+    """SO and KMP normally run on the bank-private / full-table runs kernels; the variants kept
+    for A/B measurements must give the same counts: 1 = LDS tiles (so_scan, kmp_scan),
+    2 = shared-table so_runs and the failure-link kmp_links_runs."""
     from smart_amd import engine
-    engine.tune(6, 1)
-    engine.tune(3, 1)
+    engine.tune(6, variant)
+    engine.tune(3, variant)
     try:
         for r in load_golden("fuzz_vectors.json")["rows"][::2]:
             P, T = fuzz_case(oracle, r)
