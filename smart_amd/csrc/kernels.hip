@@ -860,6 +860,16 @@ __device__ __forceinline__ void kmp_dfa_chunk(const uint4& v, uint32_t j_base, u
     }
 }
 
+// max(a, b, c) as one v_max3_u32 the optimiser cannot reassociate: written with max(), the 64
+// running-maximum steps of a run become a tree evaluated at the END of the step and all 64
+// states stay live (165 VGPRs, spills reloaded inside the loop).
+__device__ __forceinline__ uint32_t max3_now(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // The common case: 16 transitions, running maximum of the states (no hit bookkeeping).
 __device__ __forceinline__ void kmp_dfa_chunk_max(const uint4& v, uint32_t& st, uint32_t& mx)
 {
@@ -869,25 +879,88 @@ __device__ __forceinline__ void kmp_dfa_chunk_max(const uint4& v, uint32_t& st, 
         const uint32_t s1 = kmp_delta(d[q >> 2], st, q & 3);
         const uint32_t s2 = kmp_delta(d[q >> 2], s1, (q + 1) & 3);
         st = s2;
-        mx = max(max(mx, s1), s2);
+        mx = max3_now(mx, s1, s2);
     }
 }
 
+// ---------------------------------------------------------------------------
+// Runs through LDS: a wave FETCHES whole 128-byte cache lines of its 64 runs and PARKS them in
+// its slab one 64-byte half at a time.  The first version fetched 64 bytes per run and step;
+// with every run of the text in flight at once the two halves of a line were fetched a step
+// apart and BOTH missed L2 (PMC: FETCH_SIZE 1.73x the text, TCC_MISS x 128 B = 1.86 GB for
+// 1 GiB) — the data path alone, without any automaton work, took 0.236 ms per GiB.  Parking
+// whole lines instead (8 KB of slab per wave) fixed the traffic but cost waves (12 per CU
+// next to a 64 KB table), and these kernels live on occupancy: one dependent LDS lookup per
+// byte.  So the two halves of a line are requested back to back (load i: bytes 0..63 of runs
+// 16i + lane/4, load 4+i: bytes 64..127 of the same runs), held in registers, and the slab
+// stays [64 runs][64 B]: 4 KB per wave, 16 waves per CU next to any table.
+// Slab layout, unpadded: the 16-byte piece c of run R sits in slot 4R + (c ^ ((R >> 2) & 3)),
+// which makes every one of ds_read_b128's 16-lane groups cover 16 distinct slots of the
+// 256-byte bank row (no padding, no conflicts).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRunLine = 128;       // bytes of a run fetched per step
+constexpr int kLineSlab = 64 * 64;       // LDS bytes per wave
+constexpr int kRunWaves = 16;            // one 1024-thread workgroup per CU shares the table
+
+struct RunIo {
+    uint8_t* wr;         // where this lane parks its piece of load i (+ 1024*i)
+    const uint8_t* rd;   // this lane's own run in the slab
+    uint32_t rswz;       // XOR applied to the piece offset 16*c when reading
+    uint32_t loff;       // loader role: byte offset of this lane's piece inside a 16-run block
+};
+
+__device__ __forceinline__ RunIo run_io(uint8_t* slab, uint32_t lane, uint32_t run_len)
+{
+    RunIo io;
+    // loader role: piece lane&3 of run R = 16i + lane/4, so (R >> 2) & 3 = (lane >> 4) & 3
+    io.wr = slab + ((lane >> 2) * 4u + ((lane & 3u) ^ ((lane >> 4) & 3u))) * 16u;
+    io.rd = slab + 64u * lane;
+    io.rswz = 16u * ((lane >> 2) & 3u);
+    io.loff = (lane >> 2) * run_len + 16u * (lane & 3u);
+    return io;
+}
+
+__device__ __forceinline__ uint4 run_piece(const RunIo& io, int c)
+{
+    return *reinterpret_cast<const uint4*>(io.rd + ((16u * c) ^ io.rswz));
+}
+
+// the 8 loads of one line per run into the named registers n0..n7 (arrays carried across the
+// step loop would go to scratch): the two halves of a line back to back
+#define RUN_FETCH(gbase_, blk_, off_)                                              \
+    do {                                                                           \
+        const uint8_t* p_ = (gbase_) + (off_);                                     \
+        n0 = *reinterpret_cast<const uint4*>(p_ + (blk_)[0]);                      \
+        n4 = *reinterpret_cast<const uint4*>(p_ + (blk_)[0] + 64);                 \
+        n1 = *reinterpret_cast<const uint4*>(p_ + (blk_)[1]);                      \
+        n5 = *reinterpret_cast<const uint4*>(p_ + (blk_)[1] + 64);                 \
+        n2 = *reinterpret_cast<const uint4*>(p_ + (blk_)[2]);                      \
+        n6 = *reinterpret_cast<const uint4*>(p_ + (blk_)[2] + 64);                 \
+        n3 = *reinterpret_cast<const uint4*>(p_ + (blk_)[3]);                      \
+        n7 = *reinterpret_cast<const uint4*>(p_ + (blk_)[3] + 64);                 \
+    } while (0)
+#define RUN_PARK(io_, r0_, r1_, r2_, r3_)                                          \
+    do {                                                                           \
+        *reinterpret_cast<uint4*>((io_).wr) = r0_;                                 \
+        *reinterpret_cast<uint4*>((io_).wr + 1024) = r1_;                          \
+        *reinterpret_cast<uint4*>((io_).wr + 2048) = r2_;                          \
+        *reinterpret_cast<uint4*>((io_).wr + 3072) = r3_;                          \
+    } while (0)
+
 template <bool PREFIX>  // PREFIX: m > 255 — the automaton of the 255-byte prefix; hits are verified
-__global__ __launch_bounds__(1024) void kmp_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
-                                                 uint32_t dfa_off)
+__global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
+                                                       uint32_t dfa_off)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr uint32_t kWaves = 16;
     const uint32_t m = a.m;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t w = PREFIX ? kKmpDfaMaxM : m;  // length the automaton recognises = accept state
     const uint32_t table_bytes = (w + 1) * 256;
-    uint8_t* slab = smem + table_bytes + wave * kRunSlab;
+    const RunIo io = run_io(smem + table_bytes + wave * kLineSlab, lane, run_len);
     {
         const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
         uint4* t = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = threadIdx.x; i < table_bytes / 16; i += kWaves * 64) t[i] = g[i];
+        for (uint32_t i = threadIdx.x; i < table_bytes / 16; i += kRunWaves * 64) t[i] = g[i];
     }
     // the perm result IS the LDS address: the table sits at LDS offset 0 (no static LDS in
     // this kernel, so the dynamic segment starts there); a poisoned count if that ever changes
@@ -899,19 +972,18 @@ __global__ __launch_bounds__(1024) void kmp_runs(ScanArgs a, uint32_t run_len, u
 
     uint32_t hits = 0;
     const uint64_t run_first = a.s_begin / run_len;  // runs are cut on absolute offsets
-    const uint64_t nwaves = (uint64_t)gridDim.x * kWaves;
-    const uint32_t span = run_len + w - 1;           // bytes a run scans
-    const uint32_t nsteps = (span + 63) / 64;
+    const uint64_t nwaves = (uint64_t)gridDim.x * kRunWaves;
+    const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
     // group = 64 consecutive runs handled by one wave
-    for (uint64_t g = (uint64_t)blockIdx.x * kWaves + wave; g * 64 < nruns; g += nwaves) {
-        // loader role: lane covers piece (lane & 3) of runs 16*i + (lane >> 2), i = 0..3
-        const uint8_t* src[4];
+    for (uint64_t g = (uint64_t)blockIdx.x * kRunWaves + wave; g * 64 < nruns; g += nwaves) {
+        // loader addresses = wave-uniform base of the group + wave-uniform offset of the 16-run
+        // block i + ONE per-lane offset.  A block that lies entirely past the last run re-reads
+        // block 0 (loaded, never consumed); the lanes of the one block that straddles the end
+        // read at most 15 runs past it, inside the text's back pad (run_len <= 8192).
+        const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
+        uint32_t blk[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint64_t r = g * 64 + 16 * i + (lane >> 2);
-            if (r >= nruns) r = nruns - 1;  // clamp: loaded but never consumed
-            src[i] = a.text + (run_first + r) * run_len + (lane & 3u) * 16u;
-        }
+        for (int i = 0; i < 4; ++i) blk[i] = g * 64 + 16 * i < nruns ? 16u * i * run_len : 0u;
         // owner role: this lane's run and the bytes of it that count
         const uint64_t my = g * 64 + lane;
         const uint64_t seg = (run_first + my) * run_len;
@@ -921,36 +993,18 @@ __global__ __launch_bounds__(1024) void kmp_runs(ScanArgs a, uint32_t run_len, u
         const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
         const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
 
-        uint4 nx0 = *reinterpret_cast<const uint4*>(src[0]);
-        uint4 nx1 = *reinterpret_cast<const uint4*>(src[1]);
-        uint4 nx2 = *reinterpret_cast<const uint4*>(src[2]);
-        uint4 nx3 = *reinterpret_cast<const uint4*>(src[3]);
+        uint4 n0, n1, n2, n3, n4, n5, n6, n7;
+        RUN_FETCH(gbase, blk, 0u);
         uint32_t st = 0;
         bool dense = false;   // wave-uniform: the last whole step reached the accept state
         bool parked = false;  // PREFIX: first unverified prefix hit of this step
         const uint8_t* parked_at = a.text;
-        for (uint32_t k = 0; k < nsteps; ++k) {
-            // park this step's 64 bytes of every run in the slab
-            {
-                uint8_t* dst = slab + (lane >> 2) * 80u + (lane & 3u) * 16u;
-                *reinterpret_cast<uint4*>(dst) = nx0;
-                *reinterpret_cast<uint4*>(dst + 16 * 80) = nx1;
-                *reinterpret_cast<uint4*>(dst + 32 * 80) = nx2;
-                *reinterpret_cast<uint4*>(dst + 48 * 80) = nx3;
-            }
-            if (k + 1 < nsteps) {  // prefetch the next step (wave-uniform)
-                const uint32_t o = (k + 1) * 64u;
-                nx0 = *reinterpret_cast<const uint4*>(src[0] + o);
-                nx1 = *reinterpret_cast<const uint4*>(src[1] + o);
-                nx2 = *reinterpret_cast<const uint4*>(src[2] + o);
-                nx3 = *reinterpret_cast<const uint4*>(src[3] + o);
-            }
-            const uint32_t jb = k * 64u;
-            const uint8_t* mine = slab + lane * 80u;
+        // one 64-byte half of a line: the bytes [jb, jb + 64) of every run are in the slab
+        auto half = [&](const uint32_t jb) {
             // one 16-byte chunk with hit bookkeeping (run boundaries, and steps that reach state w);
             // returns whether the accept state was seen
             auto careful = [&](int q, bool whole) -> bool {
-                const uint4 v = *reinterpret_cast<const uint4*>(mine + 16 * q);
+                const uint4 v = run_piece(io, q);
                 const uint32_t j = jb + 16u * q;
                 if (!PREFIX) {
                     const uint32_t h0 = hits;
@@ -976,14 +1030,13 @@ __global__ __launch_bounds__(1024) void kmp_runs(ScanArgs a, uint32_t run_len, u
                     return seen;
                 }
             };
-            if (jb >= j0 && jb + 64u <= jend) {  // the whole step is inside the run
+            if (jb >= j0 && jb + 64u <= jend) {  // the whole half is inside the run
                 bool seen = false;
                 if (!dense) {
                     const uint32_t st0 = st;
                     uint32_t mx = 0;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        kmp_dfa_chunk_max(*reinterpret_cast<const uint4*>(mine + 16 * q), st, mx);
+                    for (int q = 0; q < 4; ++q) kmp_dfa_chunk_max(run_piece(io, q), st, mx);
                     seen = mx == w;
                     if (seen) {  // the accept state was reached: walk the step again, counting
                         st = st0;
@@ -998,7 +1051,7 @@ __global__ __launch_bounds__(1024) void kmp_runs(ScanArgs a, uint32_t run_len, u
                 // costs more than it saves: the wave counts directly while its last step saw any
                 dense = __any(seen);
             } else {
-#pragma unroll
+#pragma unroll 1
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t j = jb + 16u * q;
                     careful(q, j >= j0 && j + 16 <= jend);
@@ -1008,6 +1061,13 @@ __global__ __launch_bounds__(1024) void kmp_runs(ScanArgs a, uint32_t run_len, u
                 hits += wave_verify(parked, parked_at, a.blob + w, m - w);
                 parked = false;
             }
+        };
+        for (uint32_t k = 0; k < nlines; ++k) {
+            RUN_PARK(io, n0, n1, n2, n3);
+            half(k * kRunLine);
+            RUN_PARK(io, n4, n5, n6, n7);
+            if (k + 1 < nlines) RUN_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
+            half(k * kRunLine + 64u);
         }
     }
     flush_hits(hits, a.count);
@@ -1097,36 +1157,31 @@ __global__ __launch_bounds__(256) void kmp_links_runs(ScanArgs a, uint32_t run_l
     flush_hits(hits, a.count);
 }
 
-// Shift-Or over per-lane RUNS (the structure of kmp_runs below): with LDS tiles a
-// lane's run is 80 bytes and the w-1 bytes it re-scans to rebuild the state cost up
-// to 39 % extra work per owned byte (the kernel is VALU-bound: rocprofv3 shows 76 %
-// VALU busy); runs of 1 KiB make that 3 %.  Same recurrence as so_scan.
-template <bool LONG, int WAVES, bool BP>  // BP: bank-private table (one copy of S' per lane)
-__global__ __launch_bounds__(WAVES * 64) void so_runs(ScanArgs a, uint32_t run_len, uint64_t nruns)
+// Shift-Or over per-lane RUNS (the structure of kmp_runs above).  With LDS tiles a lane's run is
+// 80 bytes and the w-1 bytes it re-scans to rebuild the state cost up to 39 % extra work per
+// owned byte; runs of 2-4 KiB make that 1 %.  Same recurrence as so_scan.
+//
+// The S' table is BANK-PRIVATE: u32 S'[256][64], entry c of lane l at byte c*256 + l*4, i.e.
+// always in bank l (ds_read_b32 banks are (a/4) mod 32 over two 32-lane groups).  A gather of
+// 64 different bytes is then conflict-free by construction (a shared 1 KB table: 3x conflicts on
+// rand128, LDS 80 % busy — PMC), and the address is ONE v_perm_b32 (byte 1 = text byte, byte 0 =
+// 4*lane).  64 KB table + 16 slabs of 4 KB = one 1024-thread workgroup per CU.
+// so_runs64 (A/B, smartgpu_tune(6,2)): the first runs kernel — shared table, 64-byte steps.
+template <bool LONG>  // LONG: m > 32, hits of the 32-byte prefix are verified
+__global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t run_len, uint64_t nruns)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // BP = false: u32 S'[257], padded to 1040 B (S'[256] = sentinel).
-    // BP = true : u32 S'[256][64] — entry c of lane l at byte c*256 + l*4, i.e. always in bank l
-    // (ds_read_b32 banks are (a/4) mod 32 over two 32-lane groups): a gather of 64 different
-    // bytes is conflict-free by construction (shared table: 3x conflicts on rand128, measured),
-    // and the address is ONE v_perm_b32 (byte 1 = text byte, byte 0 = 4*lane).
-    constexpr uint32_t kTableBytes = BP ? 65536u : 1040u;
     uint32_t* S = reinterpret_cast<uint32_t*>(smem);
-    uint8_t* slab = smem + kTableBytes + wave * kRunSlab;
+    const RunIo io = run_io(smem + 65536 + wave * kLineSlab, lane, run_len);
     const uint32_t sentinel = 0xFFFFFFFFu << (32 - w);
-    if (BP) {
-        for (uint32_t i = threadIdx.x; i < 256 * 64; i += WAVES * 64)
-            S[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i >> 6] << (32 - w);
-    } else {
-        for (uint32_t i = threadIdx.x; i < 257; i += WAVES * 64)
-            S[i] = (i < 256 ? reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] : 0xFFFFFFFFu) << (32 - w);
-    }
+    for (uint32_t i = threadIdx.x; i < 256 * 64; i += kRunWaves * 64)
+        S[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i >> 6] << (32 - w);
     // the perm result IS the LDS address: the table sits at LDS offset 0 (this kernel has no
-    // static LDS, so the dynamic segment starts there); checked below
+    // static LDS, so the dynamic segment starts there); a poisoned count if that ever changes
     const uint32_t lane4 = lane * 4u;
-    if (BP && (uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {
         if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
         return;
     }
@@ -1134,16 +1189,13 @@ __global__ __launch_bounds__(WAVES * 64) void so_runs(ScanArgs a, uint32_t run_l
 
     uint32_t hits = 0;
     const uint64_t run_first = a.s_begin / run_len;
-    const uint64_t nwaves = (uint64_t)gridDim.x * WAVES;
-    const uint32_t nsteps = (run_len + w - 1 + 63) / 64;
-    for (uint64_t g = (uint64_t)blockIdx.x * WAVES + wave; g * 64 < nruns; g += nwaves) {
-        const uint8_t* src[4];
+    const uint64_t nwaves = (uint64_t)gridDim.x * kRunWaves;
+    const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
+    for (uint64_t g = (uint64_t)blockIdx.x * kRunWaves + wave; g * 64 < nruns; g += nwaves) {
+        const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
+        uint32_t blk[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint64_t r = g * 64 + 16 * i + (lane >> 2);
-            if (r >= nruns) r = nruns - 1;  // clamp: loaded but never consumed
-            src[i] = a.text + (run_first + r) * run_len + (lane & 3u) * 16u;
-        }
+        for (int i = 0; i < 4; ++i) blk[i] = g * 64 + 16 * i < nruns ? 16u * i * run_len : 0u;
         const uint64_t my = g * 64 + lane;
         const uint64_t seg = (run_first + my) * run_len;
         const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
@@ -1152,35 +1204,13 @@ __global__ __launch_bounds__(WAVES * 64) void so_runs(ScanArgs a, uint32_t run_l
         const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
         const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
 
-        // two steps (2 x 64 B per run, 8 KB per wave) are in flight in registers: one step per
-        // wave left the kernel latency-bound (bytes in flight per CU = rate x HBM latency, PMC)
-        uint4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
-        auto fetch = [&](uint32_t k, uint4& r0, uint4& r1, uint4& r2, uint4& r3) {
-            // unconditional (past the last step: the last step again, a cache hit), so that the
-            // number of loads in flight is static and the waits are vmcnt(4), not vmcnt(0)
-            const uint32_t o = (k < nsteps ? k : nsteps - 1) * 64u;
-            r0 = *reinterpret_cast<const uint4*>(src[0] + o);
-            r1 = *reinterpret_cast<const uint4*>(src[1] + o);
-            r2 = *reinterpret_cast<const uint4*>(src[2] + o);
-            r3 = *reinterpret_cast<const uint4*>(src[3] + o);
-        };
-        fetch(0, pa0, pa1, pa2, pa3);
-        __builtin_amdgcn_sched_barrier(0);  // keep the issue order: the loop waits with vmcnt(4)
-        fetch(1, pb0, pb1, pb2, pb3);
-        __builtin_amdgcn_sched_barrier(0);
-        uint32_t D = 0xFFFFFFFFu << (32 - w);
+        uint4 n0, n1, n2, n3, n4, n5, n6, n7;
+        RUN_FETCH(gbase, blk, 0u);
+        uint32_t D = sentinel;
         bool parked = false;
         const uint8_t* parked_at = a.text;
-        auto step = [&](uint32_t k, uint4& nx0, uint4& nx1, uint4& nx2, uint4& nx3) {
-            {
-                uint8_t* dst = slab + (lane >> 2) * 80u + (lane & 3u) * 16u;
-                *reinterpret_cast<uint4*>(dst) = nx0;
-                *reinterpret_cast<uint4*>(dst + 16 * 80) = nx1;
-                *reinterpret_cast<uint4*>(dst + 32 * 80) = nx2;
-                *reinterpret_cast<uint4*>(dst + 48 * 80) = nx3;
-            }
-            fetch(k + 2, nx0, nx1, nx2, nx3);
-            const uint8_t* mine = slab + lane * 80u;
+        // one 64-byte half of a line: the bytes [jb, jb + 64) of every run are in the slab
+        auto half = [&](const uint32_t jb) {
             // hit mask of one 16-byte chunk (bit 15-q: a window ends at byte q)
             auto take_hits = [&](uint32_t base, uint32_t hm) {
                 if (!LONG) {
@@ -1199,19 +1229,17 @@ __global__ __launch_bounds__(WAVES * 64) void so_runs(ScanArgs a, uint32_t run_l
                     }
                 }
             };
-            if (BP && k * 64u >= j0 && k * 64u + 64u <= jend) {
-                // the whole 64-byte step is inside the run (all steps but a run's first/last):
-                // straight-line code, so the 64 gathers are in flight under the recurrence
-                // (the long-pattern instantiation gathers 32 bytes at a time: its verify path
-                // needs the registers)
-                constexpr int NB = LONG ? 2 : 1;   // gather batches per step
-                constexpr int CB = 4 / NB;         // 16-byte chunks per batch
+            if (jb >= j0 && jb + 64u <= jend) {
+                // the whole half is inside the run (all but a run's first/last): straight-
+                // line code, the gathers of a batch are in flight under the recurrence
+                constexpr int CB = LONG ? 2 : 4;  // 16-byte chunks per gather batch (the long-
+                                                  // pattern instantiation needs the registers)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
+                for (int nb = 0; nb < 4 / CB; ++nb) {
                     uint32_t sv[16 * CB];
 #pragma unroll
                     for (int c4 = 0; c4 < CB; ++c4) {
-                        const uint4 v = *reinterpret_cast<const uint4*>(mine + 16 * (CB * nb + c4));
+                        const uint4 v = run_piece(io, CB * nb + c4);
                         const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                         for (int q = 0; q < 16; ++q)
@@ -1225,7 +1253,7 @@ __global__ __launch_bounds__(WAVES * 64) void so_runs(ScanArgs a, uint32_t run_l
                             D = (D << 1) | sv[32 * h + q];            // so.c:55
                             H = __builtin_amdgcn_alignbit(H, D, 31);  // so.c:56: sign bit clear <=> hit
                         }
-                        const uint32_t base = k * 64u + 16u * CB * nb + 32u * h;
+                        const uint32_t base = jb + 16u * CB * nb + 32u * h;
                         if (!LONG) {
                             hits += __popc(~H);
                         } else {
@@ -1235,6 +1263,96 @@ __global__ __launch_bounds__(WAVES * 64) void so_runs(ScanArgs a, uint32_t run_l
                     }
                 }
             } else {
+#pragma unroll 1
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const uint32_t base = jb + 16u * c4;
+                    if (base >= jend || base + 16 <= j0) continue;
+                    const uint4 v = run_piece(io, c4);
+                    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t H = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const uint32_t j = base + q;
+                        uint32_t sv = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
+                        sv = (j >= j0 && j < jend) ? sv : sentinel;
+                        D = (D << 1) | sv;
+                        H = __builtin_amdgcn_alignbit(H, D, 31);
+                    }
+                    take_hits(base, ~H & 0xFFFFu);
+                }
+            }
+            if (LONG && __any(parked)) {  // keep at most one parked window per lane
+                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
+                parked = false;
+            }
+        };
+        for (uint32_t k = 0; k < nlines; ++k) {
+            RUN_PARK(io, n0, n1, n2, n3);
+            half(k * kRunLine);
+            RUN_PARK(io, n4, n5, n6, n7);
+            if (k + 1 < nlines) RUN_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
+            half(k * kRunLine + 64u);
+        }
+    }
+    flush_hits(hits, a.count);
+}
+
+// The first runs kernel: shared 1 KB table, 64-byte steps, [run][80 B] slabs (A/B only).
+template <bool LONG>
+__global__ __launch_bounds__(256) void so_runs64(ScanArgs a, uint32_t run_len, uint64_t nruns)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m, w = m < 32 ? m : 32;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* S = reinterpret_cast<uint32_t*>(smem);  // 257 entries, padded to 1040 B
+    uint8_t* slab = smem + 1040 + wave * kRunSlab;
+    for (uint32_t i = threadIdx.x; i < 257; i += 256)
+        S[i] = (i < 256 ? reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] : 0xFFFFFFFFu) << (32 - w);
+    __syncthreads();  // the only workgroup barrier: table visible
+
+    uint32_t hits = 0;
+    const uint64_t run_first = a.s_begin / run_len;
+    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
+    const uint32_t nsteps = (run_len + w - 1 + 63) / 64;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g * 64 < nruns; g += nwaves) {
+        const uint8_t* src[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint64_t r = g * 64 + 16 * i + (lane >> 2);
+            if (r >= nruns) r = nruns - 1;  // clamp: loaded but never consumed
+            src[i] = a.text + (run_first + r) * run_len + (lane & 3u) * 16u;
+        }
+        const uint64_t my = g * 64 + lane;
+        const uint64_t seg = (run_first + my) * run_len;
+        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
+        const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
+        const bool owner = my < nruns && sa < sb;
+        const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
+        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
+
+        uint4 nx0 = *reinterpret_cast<const uint4*>(src[0]);
+        uint4 nx1 = *reinterpret_cast<const uint4*>(src[1]);
+        uint4 nx2 = *reinterpret_cast<const uint4*>(src[2]);
+        uint4 nx3 = *reinterpret_cast<const uint4*>(src[3]);
+        uint32_t D = 0xFFFFFFFFu << (32 - w);
+        bool parked = false;
+        const uint8_t* parked_at = a.text;
+        for (uint32_t k = 0; k < nsteps; ++k) {
+            {
+                uint8_t* dst = slab + (lane >> 2) * 80u + (lane & 3u) * 16u;
+                *reinterpret_cast<uint4*>(dst) = nx0;
+                *reinterpret_cast<uint4*>(dst + 16 * 80) = nx1;
+                *reinterpret_cast<uint4*>(dst + 32 * 80) = nx2;
+                *reinterpret_cast<uint4*>(dst + 48 * 80) = nx3;
+            }
+            if (k + 1 < nsteps) {
+                const uint32_t o = (k + 1) * 64u;
+                nx0 = *reinterpret_cast<const uint4*>(src[0] + o);
+                nx1 = *reinterpret_cast<const uint4*>(src[1] + o);
+                nx2 = *reinterpret_cast<const uint4*>(src[2] + o);
+                nx3 = *reinterpret_cast<const uint4*>(src[3] + o);
+            }
+            const uint8_t* mine = slab + lane * 80u;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 const uint32_t base = k * 64u + 16u * c4;
@@ -1243,18 +1361,7 @@ __global__ __launch_bounds__(WAVES * 64) void so_runs(ScanArgs a, uint32_t run_l
                 const uint32_t d[4] = {v.x, v.y, v.z, v.w};
                 const bool full = base >= j0 && base + 16 <= jend;
                 uint32_t sv[16];
-                if (BP) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        sv[q] = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
-                    if (!full) {
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const uint32_t j = base + q;
-                            sv[q] = (j >= j0 && j < jend) ? sv[q] : sentinel;
-                        }
-                    }
-                } else if (full) {
+                if (full) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) sv[q] = S[(d[q >> 2] >> (8 * (q & 3))) & 0xFFu];
                 } else {
@@ -1271,17 +1378,27 @@ __global__ __launch_bounds__(WAVES * 64) void so_runs(ScanArgs a, uint32_t run_l
                     D = (D << 1) | sv[q];                     // so.c:55
                     H = __builtin_amdgcn_alignbit(H, D, 31);  // so.c:56: sign bit clear <=> hit
                 }
-                take_hits(base, ~H & 0xFFFFu);
-            }
+                uint32_t hm = ~H & 0xFFFFu;
+                if (!LONG) {
+                    hits += __popc(hm);
+                } else {
+                    while (hm) {  // 32-byte prefix matched, ending at byte q: verify P[32..m)
+                        const uint32_t bit = 31u - __builtin_clz(hm);
+                        hm &= ~(1u << bit);
+                        const uint8_t* rest = a.text + seg + base + (15u - bit) + 1;
+                        if (!parked) {
+                            parked = true;
+                            parked_at = rest;
+                        } else {
+                            hits += global_equal(rest, a.blob + w, m - w);
+                        }
+                    }
+                }
             }
             if (LONG && __any(parked)) {  // keep at most one parked window per lane
                 hits += wave_verify(parked, parked_at, a.blob + w, m - w);
                 parked = false;
             }
-        };
-        for (uint32_t k = 0; k < nsteps; k += 2) {  // an odd nsteps runs one empty step (k*64 >= jend)
-            step(k, pa0, pa1, pa2, pa3);
-            step(k + 1, pb0, pb1, pb2, pb3);
         }
     }
     flush_hits(hits, a.count);
@@ -1596,7 +1713,7 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
         }
         case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : "kmp_runs";
-        case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : "so_runs";
+        case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : "so_runs";
         case SMARTGPU_BNDM: return (pk || (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1)) ? "packed_scan" : "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
     }
@@ -1605,44 +1722,67 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
 
 // KMP runs.  Run length: re-scan overhead (m-1)/L <= 1/8 when the text is long enough,
 // never above 1/2, short enough to give every CU ~16 waves of runs, multiple of 64.
+// Run length for the runs kernels: every wave should get the same number of groups (`per_group`
+// runs each), or the slowest wave sets the kernel time (12 waves/CU on 4096 groups: 67 %).
+// Picks the smallest k such that span / (k * nwaves groups) gives runs of at most `lmax` bytes,
+// then grows L in 64-byte steps until the runs cut on absolute offsets fit k * nwaves groups.
+// Runs shorter than `lmin` (small texts) are not worth balancing: L = lmin.
+static uint64_t balanced_run_len(uint64_t s_begin, uint64_t s_end, uint64_t per_group, uint64_t nwaves,
+                                 uint64_t lmin, uint64_t lmax)
+{
+    const uint64_t span = s_end - s_begin;
+    const uint64_t slots = per_group * nwaves;  // runs per round of all waves
+    const uint64_t k = (span + slots * lmax - 1) / (slots * lmax);
+    uint64_t L = ((span + slots * k - 1) / (slots * k) + 63) & ~63ull;
+    if (L < lmin) return (lmin + 63) & ~63ull;
+    while (tiles_for(s_begin, s_end, L).count > slots * k) L += 64;
+    return L;
+}
+
 static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream)
 {
     const uint32_t m = a.m;
     const bool links = g_tune[3] == 2;                       // failure links, A/B
     const uint32_t w = (links || m <= kKmpDfaMaxM) ? m : kKmpDfaMaxM;  // bytes re-scanned per run: w-1
-    const uint64_t span = a.s_end - a.s_begin;
-    uint64_t L = 8ull * (w - 1);
-    const uint64_t fill = span / ((uint64_t)num_cus * 16 * 64);
-    if (L > fill) L = fill;
-    if (L < 2ull * (w - 1)) L = 2ull * (w - 1);
-    const uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;  // longer runs amortise the per-run set-up
-    if (L < lmin) L = lmin;
-    L = (L + 63) & ~63ull;
-    const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
-    if (tr.count == 0) return hipSuccess;
     const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));
     if (links) {
+        const uint64_t span = a.s_end - a.s_begin;
+        uint64_t L = 8ull * (w - 1);
+        const uint64_t fill = span / ((uint64_t)num_cus * 16 * 64);
+        if (L > fill) L = fill;
+        if (L < 2ull * (w - 1)) L = 2ull * (w - 1);
+        if (L < 512) L = 512;
+        L = (L + 63) & ~63ull;
+        const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
+        if (tr.count == 0) return hipSuccess;
         const size_t lds = r16(4 * m) + 4 * (size_t)kRunSlab;
         uint64_t grid = ((uint64_t)tr.count + 255) / 256;
-        const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 4);
+        const uint64_t cap = (uint64_t)num_cus * 4;
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL(kmp_links_runs, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
                            (uint64_t)tr.count, dfa_off);
         return hipGetLastError();
     }
-    // one 1024-thread workgroup per CU: the table (up to 64 KB) is shared by 16 waves
-    const size_t lds = (size_t)(w + 1) * 256 + 16 * (size_t)kRunSlab;
-    uint64_t grid = ((uint64_t)tr.count + 1023) / 1024;
+    // one 1024-thread workgroup per CU shares the table (<= 64 KB) next to 16 x 4 KB of slabs
+    const size_t lds = (size_t)(w + 1) * 256 + kRunWaves * (size_t)kLineSlab;
+    // runs of 2-4 KiB: at least 8x the w-1 bytes a run re-scans, at most 8 KiB (the loader's
+    // over-read past the last run stays inside the text's back pad)
+    uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
+    if (lmin < 8ull * (w - 1)) lmin = 8ull * (w - 1);
+    const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin);
+    const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
+    if (tr.count == 0) return hipSuccess;
+    uint64_t grid = ((uint64_t)tr.count + 64ull * kRunWaves - 1) / (64ull * kRunWaves);
     if (grid > (uint64_t)num_cus) grid = num_cus;
     const void* fn = m > kKmpDfaMaxM ? reinterpret_cast<const void*>(kmp_runs<true>)
                                      : reinterpret_cast<const void*>(kmp_runs<false>);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (m > kKmpDfaMaxM)
-        hipLaunchKernelGGL(kmp_runs<true>, dim3((uint32_t)grid), dim3(1024), lds, stream, a, (uint32_t)L,
-                           (uint64_t)tr.count, dfa_off);
+        hipLaunchKernelGGL(kmp_runs<true>, dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a,
+                           (uint32_t)L, (uint64_t)tr.count, dfa_off);
     else
-        hipLaunchKernelGGL(kmp_runs<false>, dim3((uint32_t)grid), dim3(1024), lds, stream, a, (uint32_t)L,
-                           (uint64_t)tr.count, dfa_off);
+        hipLaunchKernelGGL(kmp_runs<false>, dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a,
+                           (uint32_t)L, (uint64_t)tr.count, dfa_off);
     return hipGetLastError();
 }
 
@@ -1740,8 +1880,8 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             return launch_tiled(bndm_scan<kBndmT, kBndmL, false>, a, tr, kBndmT, lds, 8, num_cus, stream);
         }
         case SMARTGPU_SO: {
-            if (g_tune[6] != 1) {  // per-lane runs through LDS slabs (tune[6]=1: LDS tiles, for A/B)
-                uint64_t L = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
+            if (g_tune[6] == 2) {  // the first runs kernel: shared table, 64-byte steps (A/B)
+                uint64_t L = g_tune[5] ? (uint64_t)g_tune[5] : 1024;
                 const uint64_t fill = (a.s_end - a.s_begin) / ((uint64_t)num_cus * 16 * 64);
                 if (L > fill) L = fill;
                 if (L < 256) L = 256;
@@ -1749,27 +1889,31 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
                 if (tr.count == 0) return hipSuccess;
                 uint64_t grid = ((uint64_t)tr.count + 255) / 256;
-                const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 6);
+                const uint64_t cap = (uint64_t)num_cus * 6;
                 if (grid > cap) grid = cap;
-                if (g_tune[6] == 2) {  // shared table, 256-thread workgroups (A/B)
-                    const size_t lds = 1040 + 4 * (size_t)kRunSlab;
-                    if (m > 32)
-                        hipLaunchKernelGGL((so_runs<true, 4, false>), dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
-                    else
-                        hipLaunchKernelGGL((so_runs<false, 4, false>), dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
-                    return hipGetLastError();
-                }
+                const size_t lds = 1040 + 4 * (size_t)kRunSlab;
+                if (m > 32)
+                    hipLaunchKernelGGL(so_runs64<true>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                else
+                    hipLaunchKernelGGL(so_runs64<false>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                return hipGetLastError();
+            }
+            if (g_tune[6] != 1) {  // per-lane runs through LDS line slabs (tune[6]=1: LDS tiles, for A/B)
                 // bank-private table: 64 KB shared by the 16 waves of ONE workgroup per CU
-                const size_t lds = 65536 + 16 * (size_t)kRunSlab;
-                grid = ((uint64_t)tr.count + 1023) / 1024;
+                const uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
+                const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin);
+                const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
+                if (tr.count == 0) return hipSuccess;
+                const size_t lds = 65536 + kRunWaves * (size_t)kLineSlab;
+                uint64_t grid = ((uint64_t)tr.count + 64ull * kRunWaves - 1) / (64ull * kRunWaves);
                 if (grid > (uint64_t)num_cus) grid = num_cus;
-                const void* fn = m > 32 ? reinterpret_cast<const void*>(so_runs<true, 16, true>)
-                                        : reinterpret_cast<const void*>(so_runs<false, 16, true>);
+                const void* fn = m > 32 ? reinterpret_cast<const void*>(so_runs<true>)
+                                        : reinterpret_cast<const void*>(so_runs<false>);
                 (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (m > 32)
-                    hipLaunchKernelGGL((so_runs<true, 16, true>), dim3((uint32_t)grid), dim3(1024), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                    hipLaunchKernelGGL(so_runs<true>, dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
                 else
-                    hipLaunchKernelGGL((so_runs<false, 16, true>), dim3((uint32_t)grid), dim3(1024), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                    hipLaunchKernelGGL(so_runs<false>, dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
                 return hipGetLastError();
             }
             const size_t lds = 1040 + (size_t)kSoT * kSoL + 32;
