@@ -894,6 +894,10 @@ __device__ __forceinline__ void kmp_dfa_chunk_max(const uint4& v, uint32_t& st, 
 // byte.  So the two halves of a line are requested back to back (load i: bytes 0..63 of runs
 // 16i + lane/4, load 4+i: bytes 64..127 of the same runs), held in registers, and the slab
 // stays [64 runs][64 B]: 4 KB per wave, 16 waves per CU next to any table.
+// Tried and dropped (measured on rand128, 1 GiB): two runs per lane with interleaved lookups
+// (57-59 % against 65-67 %), groups handed out by a device-wide atomic counter (same-address
+// atomics serialise at ~16 ns and, returning through vmcnt, stall every wave's first fetch:
+// 40-54 %), groups drawn from a per-workgroup LDS counter (no gain over equal static shares).
 // Slab layout, unpadded: the 16-byte piece c of run R sits in slot 4R + (c ^ ((R >> 2) & 3)),
 // which makes every one of ds_read_b128's 16-lane groups cover 16 distinct slots of the
 // 256-byte bank row (no padding, no conflicts).
@@ -1176,8 +1180,13 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
     uint32_t* S = reinterpret_cast<uint32_t*>(smem);
     const RunIo io = run_io(smem + 65536 + wave * kLineSlab, lane, run_len);
     const uint32_t sentinel = 0xFFFFFFFFu << (32 - w);
-    for (uint32_t i = threadIdx.x; i < 256 * 64; i += kRunWaves * 64)
-        S[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i >> 6] << (32 - w);
+    {   // expand the 256 masks to one copy per lane through a 1 KB staging area (wave 0's slab):
+        // one global load per thread instead of 16 dependent broadcast loads
+        uint32_t* stage = reinterpret_cast<uint32_t*>(smem + 65536);
+        if (threadIdx.x < 256) stage[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[threadIdx.x] << (32 - w);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 256 * 64; i += kRunWaves * 64) S[i] = stage[i >> 6];
+    }
     // the perm result IS the LDS address: the table sits at LDS offset 0 (this kernel has no
     // static LDS, so the dynamic segment starts there); a poisoned count if that ever changes
     const uint32_t lane4 = lane * 4u;
