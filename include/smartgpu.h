@@ -52,7 +52,12 @@ enum {
     SMARTGPU_SO = 3,   /* src/algos/so.c   */
     SMARTGPU_BNDM = 4, /* src/algos/bndm.c */
     SMARTGPU_EPSM = 5, /* src/algos/epsm.c */
-    SMARTGPU_NUM_ALGOS = 6
+    /* adjacent algorithm names on the same engine */
+    SMARTGPU_SA = 6,      /* src/algos/sa.c      Shift-And, the dual of so.c            */
+    SMARTGPU_QS = 7,      /* src/algos/qs.c      Quick Search: shift on the byte after the window */
+    SMARTGPU_TUNEDBM = 8, /* src/algos/tunedbm.c Horspool's table with a zero entry + skip loop   */
+    SMARTGPU_RAITA = 9,   /* src/algos/raita.c   Horspool's shifts, last/middle/first/rest order; m >= 2 (raita.c:37) */
+    SMARTGPU_NUM_ALGOS = 10
 };
 
 typedef struct smartgpu_text smartgpu_text; /* a text resident in one GPU's HBM */
@@ -62,7 +67,7 @@ typedef struct smartgpu_plan smartgpu_plan; /* one (algorithm, pattern) with its
 const char *smartgpu_version(void);
 const char *smartgpu_last_error(void);
 int smartgpu_device_count(void);                   /* <0 on error */
-int smartgpu_algo_id(const char *name);            /* "hor","bm","kmp","so","bndm","epsm" (any case); -1 unknown */
+int smartgpu_algo_id(const char *name);            /* "hor","bm","kmp","so","bndm","epsm","sa","qs","tunedbm","raita" (any case); -1 unknown */
 const char *smartgpu_algo_name(int algo);          /* NULL if out of range */
 int smartgpu_device_sync(int device);              /* waits for the library's stream on `device` */
 
@@ -103,6 +108,10 @@ int smartgpu_kmp_search(const unsigned char *P, int m, const unsigned char *T, i
 int smartgpu_so_search(const unsigned char *P, int m, const unsigned char *T, int n);
 int smartgpu_bndm_search(const unsigned char *P, int m, const unsigned char *T, int n);
 int smartgpu_epsm_search(const unsigned char *P, int m, const unsigned char *T, int n);
+int smartgpu_sa_search(const unsigned char *P, int m, const unsigned char *T, int n);      /* sa.c:36-94 */
+int smartgpu_qs_search(const unsigned char *P, int m, const unsigned char *T, int n);      /* qs.c:33-52 */
+int smartgpu_tunedbm_search(const unsigned char *P, int m, const unsigned char *T, int n); /* tunedbm.c:36-65 */
+int smartgpu_raita_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* raita.c:35-64; -1 for m < 2 */
 /* pre/run times (ms) of the last search on this thread (main.h:34-35 globals) */
 void smartgpu_last_times(double *pre_ms, double *run_ms);
 
@@ -178,7 +187,8 @@ int smartgpu_tune(int key, int value);
  *          4 BNDM masks (256)             bndm.c:35-40 (same)
  *          5 KMP transition table ((m+1)*256, m <= 255): the failure links of kmp.c:27-41
  *            expanded into delta[state][byte]; state m = an occurrence ends here
- *          6 the same over the pattern's own alphabet: k1, colmap[256], table[(m+1)*k1]    */
+ *          6 the same over the pattern's own alphabet: k1, colmap[256], table[(m+1)*k1]
+ *          7 Shift-And masks S[256] (sa.c:27-34), 8 Quick Search shifts qsBc[256] (qs.c:27-31)   */
 int smartgpu_build_table(int which, const uint8_t *P, uint32_t m, int32_t *out, uint32_t cap);
 
 #ifdef __cplusplus

@@ -396,6 +396,108 @@ uint64_t oracle_epsm(const uint8_t *P, int m, const uint8_t *T, uint64_t n)
 }
 
 /* ------------------------------------------------------------------ */
+/* Adjacent algorithms on the same engine.           */
+/* ------------------------------------------------------------------ */
+
+/* Shift-And: the dual of Shift-Or (a set bit = "prefix of that length
+ * ends here").  reference: preSA src/algos/sa.c:27-34, search sa.c:36-56,
+ * search_large (m > 32: 32-byte prefix + verification) sa.c:64-94.
+ * Like oracle_so, the long-pattern path only accepts windows inside T. */
+uint64_t oracle_sa(const uint8_t *P, int m, const uint8_t *T, uint64_t n)
+{
+    if (m <= 0 || (uint64_t)m > n) return 0;
+    const int w = m < 32 ? m : 32;
+    uint32_t S[ORACLE_SIGMA];
+    memset(S, 0, sizeof S);
+    for (int i = 0; i < w; ++i) S[P[i]] |= 1u << i;
+    const uint32_t final = 1u << (w - 1);
+    uint64_t hits = 0;
+    uint32_t D = 0;
+    for (uint64_t j = 0; j < n; ++j) {
+        D = ((D << 1) | 1u) & S[T[j]];
+        if (D & final) {
+            const uint64_t s = j + 1 - (uint64_t)w;
+            if (m == w) { ++hits; continue; }
+            if (s + (uint64_t)m > n) continue;
+            int k = w;
+            while (k < m && P[k] == T[s + k]) ++k;
+            hits += (k == m);
+        }
+    }
+    return hits;
+}
+
+/* Quick Search: the shift is read from the byte AFTER the window.
+ * reference: preQsBc src/algos/qs.c:27-31, search qs.c:33-52.  The
+ * reference reads T[n] for the last window (its value no longer matters);
+ * this restatement does not. */
+uint64_t oracle_qs(const uint8_t *P, int m, const uint8_t *T, uint64_t n)
+{
+    if (m <= 0 || (uint64_t)m > n) return 0;
+    int32_t shift[ORACLE_SIGMA];
+    for (int c = 0; c < ORACLE_SIGMA; ++c) shift[c] = m + 1;
+    for (int i = 0; i < m; ++i) shift[P[i]] = m - i;
+    uint64_t hits = 0, s = 0;
+    const uint64_t last = n - (uint64_t)m;
+    while (s <= last) {
+        int k = 0;
+        while (k < m && P[k] == T[s + k]) ++k;
+        hits += (k == m);
+        if (s == last) break;
+        s += (uint64_t)shift[T[s + m]];
+    }
+    return hits;
+}
+
+/* Tuned Boyer-Moore: Horspool's table with a zero for the pattern's last
+ * byte drives a skip loop; a candidate is compared and the window then
+ * moves by the shift the zero replaced.  reference: src/algos/tunedbm.c:27-65
+ * (it plants m copies of P[m-1] after the text as a sentinel, :41; here the
+ * skip loop checks the bound instead). */
+uint64_t oracle_tunedbm(const uint8_t *P, int m, const uint8_t *T, uint64_t n)
+{
+    if (m <= 0 || (uint64_t)m > n) return 0;
+    int32_t bc[ORACLE_SIGMA];
+    oracle_pre_hor(P, m, bc);
+    const int32_t after = bc[P[m - 1]];
+    bc[P[m - 1]] = 0;
+    uint64_t hits = 0, s = 0;
+    const uint64_t last = n - (uint64_t)m;
+    while (s <= last) {
+        int32_t k;
+        while ((k = bc[T[s + m - 1]]) != 0) {
+            s += (uint64_t)k;
+            if (s > last) return hits;
+        }
+        hits += (memcmp(P, T + s, (size_t)m - 1) == 0);
+        s += (uint64_t)after;
+    }
+    return hits;
+}
+
+/* Raita: Horspool's shifts; the window is tested last byte, middle byte,
+ * first byte, then the rest.  reference: src/algos/raita.c:27-64 (returns
+ * -1 for m < 2, :37 — here: brute force, the count is defined anyway). */
+uint64_t oracle_raita(const uint8_t *P, int m, const uint8_t *T, uint64_t n)
+{
+    if (m <= 0 || (uint64_t)m > n) return 0;
+    if (m < 2) return oracle_bf(P, m, T, n);
+    int32_t bc[ORACLE_SIGMA];
+    oracle_pre_hor(P, m, bc);
+    const uint8_t first = P[0], middle = P[m / 2], lastc = P[m - 1];
+    uint64_t hits = 0, s = 0;
+    const uint64_t last = n - (uint64_t)m;
+    while (s <= last) {
+        const uint8_t c = T[s + m - 1];
+        if (c == lastc && T[s + m / 2] == middle && T[s] == first &&
+            memcmp(P + 1, T + s + 1, (size_t)m - 2) == 0)
+            ++hits;
+        s += (uint64_t)bc[c];
+    }
+    return hits;
+}
+
+/* ------------------------------------------------------------------ */
 /* dispatch                                                            */
 /* ------------------------------------------------------------------ */
 typedef uint64_t (*oracle_fn)(const uint8_t *, int, const uint8_t *, uint64_t);
@@ -405,7 +507,8 @@ static oracle_fn lookup(const char *name)
     static const struct { const char *name; oracle_fn fn; } tab[] = {
         {"bf", oracle_bf},     {"hor", oracle_hor},   {"bm", oracle_bm},
         {"kmp", oracle_kmp},   {"so", oracle_so},     {"bndm", oracle_bndm},
-        {"epsm", oracle_epsm},
+        {"epsm", oracle_epsm}, {"sa", oracle_sa},     {"qs", oracle_qs},
+        {"tunedbm", oracle_tunedbm}, {"raita", oracle_raita},
     };
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i)
         if (strcmp(tab[i].name, name) == 0) return tab[i].fn;

@@ -39,8 +39,13 @@ uint64_t oracle_kmp(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
 uint64_t oracle_so(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
 uint64_t oracle_bndm(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
 uint64_t oracle_epsm(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
+/* adjacent algorithms: sa.c, qs.c, tunedbm.c, raita.c */
+uint64_t oracle_sa(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
+uint64_t oracle_qs(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
+uint64_t oracle_tunedbm(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
+uint64_t oracle_raita(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
 
-/* name in {"bf","hor","bm","kmp","so","bndm","epsm"}; returns -1 for an
+/* name in {"bf","hor","bm","kmp","so","bndm","epsm","sa","qs","tunedbm","raita"}; returns -1 for an
  * unknown name or a count that does not fit an int (SMART's -1 convention,
  * src/algos/include/main.h:39 and e.g. ssef.c:41). */
 int oracle_search_int(const char *name, const uint8_t *P, int m,

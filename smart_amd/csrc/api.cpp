@@ -121,7 +121,7 @@ struct smartgpu_plan {
 
 namespace {
 
-const char* kAlgoNames[SMARTGPU_NUM_ALGOS] = {"hor", "bm", "kmp", "so", "bndm", "epsm"};
+const char* kAlgoNames[SMARTGPU_NUM_ALGOS] = {"hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita"};
 
 smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
 {
@@ -185,6 +185,8 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
     };
     *halo = std::min<uint32_t>(m - 1, sg::kHaloMax);
     switch (algo) {
+        case SMARTGPU_TUNEDBM:  // tunedbm.c:38-40: the same table with a zero for P[m-1] — the flag bit below
+        case SMARTGPU_RAITA:    // raita.c:43: the same table
         case SMARTGPU_HOR: {
             const std::vector<int32_t> bc = sg::bad_char(P, m);
             std::vector<uint16_t> tab(256);
@@ -255,6 +257,22 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         case SMARTGPU_EPSM:
             append_fingerprint();
             break;
+        case SMARTGPU_SA: {
+            const std::vector<uint32_t> S = sg::shift_and_masks(P, m);
+            append(S.data(), 1024);
+            break;
+        }
+        case SMARTGPU_QS: {  // same layout as HOR: u16 table, 256 spare bytes, fingerprint
+            const std::vector<int32_t> qs = sg::quick_search_shifts(P, m);
+            std::vector<uint16_t> tab(256);
+            for (int c = 0; c < 256; ++c) tab[c] = static_cast<uint16_t>(qs[c]);
+            append(tab.data(), 512);
+            const uint8_t spare[256] = {0};
+            append(spare, 256);
+            append_fingerprint();  // packed regime
+            *prefer_packed = tiny_shifts(sg::bad_char(P, m));
+            break;
+        }
     }
     blob.resize((blob.size() + 255) & ~size_t(255), 0);
     return blob;
@@ -264,6 +282,7 @@ int check_search_args(int algo, const uint8_t* P, uint32_t m, const smartgpu_tex
                       uint64_t off, uint64_t n)
 {
     if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS) { set_error("unknown algorithm id %d", algo); return SMARTGPU_ERR_ARG; }
+    if (algo == SMARTGPU_RAITA && m < 2) { set_error("raita: not applicable for m < 2 (raita.c:37)"); return SMARTGPU_NA; }
     if (!P || m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return SMARTGPU_ERR_ARG; }
     if (!text) { set_error("text handle is NULL"); return SMARTGPU_ERR_ARG; }
     if (off > text->n || n > text->n - off) { set_error("range [%llu,+%llu) outside the text (%llu bytes)", (unsigned long long)off, (unsigned long long)n, (unsigned long long)text->n); return SMARTGPU_ERR_ARG; }
@@ -412,6 +431,7 @@ smartgpu_plan* smartgpu_plan_create(int algo, const uint8_t* P, uint32_t m, int 
 {
     if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS) { set_error("unknown algorithm id %d", algo); return nullptr; }
     if (!P || m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return nullptr; }
+    if (algo == SMARTGPU_RAITA && m < 2) { set_error("raita: not applicable for m < 2 (raita.c:37)"); return nullptr; }
     DeviceCtx* d = device_ctx(device);
     if (!d) return nullptr;
     const double t0 = now_ms();
@@ -624,6 +644,10 @@ int smartgpu_kmp_search(const unsigned char* P, int m, const unsigned char* T, i
 int smartgpu_so_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_SO, P, m, T, n); }
 int smartgpu_bndm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_BNDM, P, m, T, n); }
 int smartgpu_epsm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_EPSM, P, m, T, n); }
+int smartgpu_sa_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_SA, P, m, T, n); }
+int smartgpu_qs_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_QS, P, m, T, n); }
+int smartgpu_tunedbm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_TUNEDBM, P, m, T, n); }
+int smartgpu_raita_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_RAITA, P, m, T, n); }
 
 /* ---- one process, several GPUs ------------------------------------------ */
 }  // extern "C"
@@ -745,6 +769,7 @@ int smartgpu_msearch64(int algo, const uint8_t* P, uint32_t m, smartgpu_mtext* t
 {
     if (!text) { set_error("text handle is NULL"); return SMARTGPU_ERR_ARG; }
     if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS) { set_error("unknown algorithm id %d", algo); return SMARTGPU_ERR_ARG; }
+    if (algo == SMARTGPU_RAITA && m < 2) { set_error("raita: not applicable for m < 2 (raita.c:37)"); return SMARTGPU_NA; }
     if (!P || m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return SMARTGPU_ERR_ARG; }
     const int k = static_cast<int>(text->devices.size());
     // preprocessing: the tables are placed on every device
@@ -851,6 +876,8 @@ int smartgpu_build_table(int which, const uint8_t* P, uint32_t m, int32_t* out, 
             v.insert(v.end(), d.begin(), d.end());
             break;
         }
+        case 7: { auto sa = sg::shift_and_masks(P, m); v.assign(sa.begin(), sa.end()); break; }
+        case 8: v = sg::quick_search_shifts(P, m); break;
         default: set_error("unknown table %d", which); return SMARTGPU_ERR_ARG;
     }
     if (v.size() > cap) { set_error("table needs %zu entries, cap %u", v.size(), cap); return SMARTGPU_ERR_ARG; }

@@ -151,7 +151,17 @@ __device__ __forceinline__ uint32_t wave_verify(bool has, const uint8_t* tptr,
 // tab[c] = hbc[c] | 0x8000 when c == P[m-1]: the byte that selects the shift
 // also answers the first comparison, so a window costs two LDS reads.
 // ---------------------------------------------------------------------------
-template <int THREADS, int L, bool LONG>  // LONG: m-1 > back halo, windows are completed in HBM
+// VAR selects the member of the Horspool family — same tiles, same table
+// layout, same verification machinery:
+//   0  Horspool (hor.c) and Tuned BM (tunedbm.c:38-58: its zero table entry for P[m-1] and the
+//      shift applied after a candidate are exactly the flag bit and the shift stored beside it;
+//      its 3x-unrolled skip loop is this loop)
+//   1  Raita (raita.c:52-60): Horspool's shifts; a candidate is tested last byte (the flag),
+//      middle byte, first byte, then the rest — when the window is in LDS (m-1 <= halo); longer
+//      windows are tested right to left through the halo and completed in memory as in 0
+//   2  Quick Search (qs.c:27-52): the shift comes from the byte AFTER the window, T[s+m]; the
+//      tile carries 16 more bytes at its end for it
+template <int THREADS, int L, bool LONG, int VAR>  // LONG: m-1 > back halo, windows are completed in HBM
 __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_first,
                                                     uint32_t ntiles)
 {
@@ -171,7 +181,9 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
     const uint64_t t_end = tile_first + ntiles;
     static_assert(TB == THREADS * 64, "prefetch registers are written out for L = 64");
     uint4 p0, p1, p2, p3, ph;  // prefetch registers: 4 tile rows + one halo chunk
+    uint4 pf;                  // VAR 2: the 16 bytes after the tile (thread 0)
     const bool halo_lane = threadIdx.x * 16u < H16;
+    const uint8_t plast = a.blob[m - 1];
     auto issue = [&](uint64_t tile0) {
         const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
         p0 = ld_stream16(src);
@@ -179,6 +191,7 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
         p2 = ld_stream16(src + THREADS * 32);
         p3 = ld_stream16(src + THREADS * 48);
         if (halo_lane) ph = ld_stream16(src - H16);
+        if (VAR == 2 && threadIdx.x == 0) pf = *reinterpret_cast<const uint4*>(a.text + tile0 + TB);  // read again as the next tile's first row
     };
     uint64_t t = tile_first + blockIdx.x;
     issue(t * TB);
@@ -192,6 +205,7 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
             *reinterpret_cast<uint4*>(dst + THREADS * 32) = p2;
             *reinterpret_cast<uint4*>(dst + THREADS * 48) = p3;
             if (halo_lane) *reinterpret_cast<uint4*>(txt + threadIdx.x * 16u) = ph;
+            if (VAR == 2 && threadIdx.x == 0) *reinterpret_cast<uint4*>(txt + H16 + TB) = pf;
         }
         __syncthreads();
         if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
@@ -204,11 +218,16 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
             uint32_t e = (uint32_t)(lo - tile0) + H16;
             const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
             while (e < ehi) {
-                const uint32_t ent = tab[txt[e]];
-                if (ent & 0x8000u) {
+                const uint32_t ent = VAR == 2 ? tab[txt[e + 1]] : tab[txt[e]];
+                if (VAR == 2 ? txt[e] == plast : (ent & 0x8000u) != 0) {
                     uint32_t k = 1;  // bytes matched so far, right to left
+                    if (VAR == 1 && !LONG) {  // raita.c:56-57: middle byte, first byte
+                        const uint32_t mid = m / 2;
+                        if (txt[e - (m - 1) + mid] != ptail[H - (m - 1 - mid)] || txt[e - (m - 1)] != ptail[H - (m - 1)])
+                            k = H + 2;  // not a match
+                    }
                     while (k <= H && ptail[H - k] == txt[e - k]) ++k;
-                    bool ok = k > H;
+                    bool ok = k == H + 1;
                     if (LONG && ok) {  // the rest of the window is not in LDS
                         const uint8_t* rest = a.text + tile0 + (e - H16) - (m - 1);
                         if (!parked) {
@@ -1171,7 +1190,11 @@ __global__ __launch_bounds__(256) void kmp_links_runs(ScanArgs a, uint32_t run_l
 // rand128, LDS 80 % busy — PMC), and the address is ONE v_perm_b32 (byte 1 = text byte, byte 0 =
 // 4*lane).  64 KB table + 16 slabs of 4 KB = one 1024-thread workgroup per CU.
 // so_runs64 (A/B, smartgpu_tune(6,2)): the first runs kernel — shared table, 64-byte steps.
-template <bool LONG>  // LONG: m > 32, hits of the 32-byte prefix are verified
+// AND = true: Shift-And (sa.c:36-94), the dual recurrence on the same machinery: a SET bit means
+// "a prefix of that length ends here", D = ((D << 1) | 1) & S[c], hit <=> bit w-1 set.  Left-
+// aligned like SO: the 1 enters at bit 32-w, the hit is the sign bit, bytes outside a lane's
+// range map to the mask 0 (no prefix survives).
+template <bool LONG, bool AND>  // LONG: m > 32, hits of the 32-byte prefix are verified
 __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t run_len, uint64_t nruns)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1179,7 +1202,9 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* S = reinterpret_cast<uint32_t*>(smem);
     const RunIo io = run_io(smem + 65536 + wave * kLineSlab, lane, run_len);
-    const uint32_t sentinel = 0xFFFFFFFFu << (32 - w);
+    const uint32_t sentinel = AND ? 0u : 0xFFFFFFFFu << (32 - w);  // mask of a byte outside the lane's range
+    const uint32_t one = 1u << (32 - w);                          // AND: the bit shifted in
+    const uint32_t hinit = AND ? 0u : 0xFFFFFFFFu;                 // hit collector before any hit
     {   // expand the 256 masks to one copy per lane through a 1 KB staging area (wave 0's slab):
         // one global load per thread instead of 16 dependent broadcast loads
         uint32_t* stage = reinterpret_cast<uint32_t*>(smem + 65536);
@@ -1215,7 +1240,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
 
         uint4 n0, n1, n2, n3, n4, n5, n6, n7;
         RUN_FETCH(gbase, blk, 0u);
-        uint32_t D = sentinel;
+        uint32_t D = sentinel;  // SO: all ones, SA: zero — no prefix matched yet
         bool parked = false;
         const uint8_t* parked_at = a.text;
         // one 64-byte half of a line: the bytes [jb, jb + 64) of every run are in the slab
@@ -1256,18 +1281,20 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
                     }
 #pragma unroll
                     for (int h = 0; h < CB / 2; ++h) {
-                        uint32_t H = 0xFFFFFFFFu;
+                        uint32_t H = hinit;
 #pragma unroll
                         for (int q = 0; q < 32; ++q) {
-                            D = (D << 1) | sv[32 * h + q];            // so.c:55
-                            H = __builtin_amdgcn_alignbit(H, D, 31);  // so.c:56: sign bit clear <=> hit
+                            if (AND) D = ((D << 1) | one) & sv[32 * h + q];  // sa.c:52
+                            else D = (D << 1) | sv[32 * h + q];              // so.c:55
+                            H = __builtin_amdgcn_alignbit(H, D, 31);  // so.c:56 / sa.c:53: the sign bit is the hit test
                         }
+                        const uint32_t hm = AND ? H : ~H;
                         const uint32_t base = jb + 16u * CB * nb + 32u * h;
                         if (!LONG) {
-                            hits += __popc(~H);
+                            hits += __popc(hm);
                         } else {
-                            take_hits(base, ~H >> 16);
-                            take_hits(base + 16u, ~H & 0xFFFFu);
+                            take_hits(base, hm >> 16);
+                            take_hits(base + 16u, hm & 0xFFFFu);
                         }
                     }
                 }
@@ -1278,16 +1305,17 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
                     if (base >= jend || base + 16 <= j0) continue;
                     const uint4 v = run_piece(io, c4);
                     const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-                    uint32_t H = 0xFFFFFFFFu;
+                    uint32_t H = hinit;
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const uint32_t j = base + q;
                         uint32_t sv = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
                         sv = (j >= j0 && j < jend) ? sv : sentinel;
-                        D = (D << 1) | sv;
+                        if (AND) D = ((D << 1) | one) & sv;
+                        else D = (D << 1) | sv;
                         H = __builtin_amdgcn_alignbit(H, D, 31);
                     }
-                    take_hits(base, ~H & 0xFFFFu);
+                    take_hits(base, (AND ? H : ~H) & 0xFFFFu);
                 }
             }
             if (LONG && __any(parked)) {  // keep at most one parked window per lane
@@ -1716,10 +1744,14 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
 {
     const bool pk = prefer_packed && g_tune[0] == 0;
     switch (algo) {
+        case SMARTGPU_TUNEDBM:
         case SMARTGPU_HOR: {
             const int r = pk ? 3 : hor_regime(m);
             return r == 3 ? "packed_scan" : r == 2 ? "hor_scan_bp" : "hor_scan";
         }
+        case SMARTGPU_RAITA:
+        case SMARTGPU_QS: return (pk || hor_regime(m) == 3) ? "packed_scan" : "hor_scan";
+        case SMARTGPU_SA: return "so_runs";
         case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : "kmp_runs";
         case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : "so_runs";
@@ -1845,6 +1877,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
     if (a.s_end <= a.s_begin) return hipSuccess;
     const uint32_t m = a.m;
     switch (algo) {
+        case SMARTGPU_TUNEDBM:  // hor_scan<.., 0> is Tuned BM's loop (see the kernel's comment)
         case SMARTGPU_HOR: {
             const uint32_t H = a.halo;
             const int regime = (a.prefer_packed && g_tune[0] == 0) ? 3 : hor_regime(m);
@@ -1860,8 +1893,25 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             }
             const size_t lds = 512 + r16(H + 1) + r16(H) + (size_t)kHorT * kHorL;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
-            if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true>, a, tr, kHorT, lds, 8, num_cus, stream);
-            return launch_tiled(hor_scan<kHorT, kHorL, false>, a, tr, kHorT, lds, 8, num_cus, stream);
+            if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 0>, a, tr, kHorT, lds, 8, num_cus, stream);
+            return launch_tiled(hor_scan<kHorT, kHorL, false, 0>, a, tr, kHorT, lds, 8, num_cus, stream);
+        }
+        case SMARTGPU_RAITA:
+        case SMARTGPU_QS: {  // the Horspool family on hor_scan's tiles; short patterns: packed regime as HOR
+            const uint32_t H = a.halo;
+            if ((a.prefer_packed && g_tune[0] == 0) || hor_regime(m) == 3) {
+                ScanArgs b = a;
+                b.fp_off = kTableOff + 768;
+                return launch_packed<SMARTGPU_HOR>(b, num_cus, stream);
+            }
+            const size_t lds = 512 + r16(H + 1) + r16(H) + (size_t)kHorT * kHorL + 16;
+            const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
+            if (algo == SMARTGPU_QS) {
+                if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 2>, a, tr, kHorT, lds, 8, num_cus, stream);
+                return launch_tiled(hor_scan<kHorT, kHorL, false, 2>, a, tr, kHorT, lds, 8, num_cus, stream);
+            }
+            if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 1>, a, tr, kHorT, lds, 8, num_cus, stream);
+            return launch_tiled(hor_scan<kHorT, kHorL, false, 1>, a, tr, kHorT, lds, 8, num_cus, stream);
         }
         case SMARTGPU_BM: {
             if ((m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
@@ -1888,8 +1938,9 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true>, a, tr, kBndmT, lds, 8, num_cus, stream);
             return launch_tiled(bndm_scan<kBndmT, kBndmL, false>, a, tr, kBndmT, lds, 8, num_cus, stream);
         }
+        case SMARTGPU_SA:  // Shift-And: so_runs<.., AND = true>; the A/B kernels below are Shift-Or only
         case SMARTGPU_SO: {
-            if (g_tune[6] == 2) {  // the first runs kernel: shared table, 64-byte steps (A/B)
+            if (g_tune[6] == 2 && algo == SMARTGPU_SO) {  // the first runs kernel: shared table, 64-byte steps (A/B)
                 uint64_t L = g_tune[5] ? (uint64_t)g_tune[5] : 1024;
                 const uint64_t fill = (a.s_end - a.s_begin) / ((uint64_t)num_cus * 16 * 64);
                 if (L > fill) L = fill;
@@ -1907,7 +1958,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                     hipLaunchKernelGGL(so_runs64<false>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
                 return hipGetLastError();
             }
-            if (g_tune[6] != 1) {  // per-lane runs through LDS line slabs (tune[6]=1: LDS tiles, for A/B)
+            if (g_tune[6] != 1 || algo == SMARTGPU_SA) {  // per-lane runs through LDS line slabs (tune[6]=1: LDS tiles, for A/B)
                 // bank-private table: 64 KB shared by the 16 waves of ONE workgroup per CU
                 const uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
                 const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin);
@@ -1916,13 +1967,16 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 const size_t lds = 65536 + kRunWaves * (size_t)kLineSlab;
                 uint64_t grid = ((uint64_t)tr.count + 64ull * kRunWaves - 1) / (64ull * kRunWaves);
                 if (grid > (uint64_t)num_cus) grid = num_cus;
-                const void* fn = m > 32 ? reinterpret_cast<const void*>(so_runs<true>)
-                                        : reinterpret_cast<const void*>(so_runs<false>);
-                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (m > 32)
-                    hipLaunchKernelGGL(so_runs<true>, dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
-                else
-                    hipLaunchKernelGGL(so_runs<false>, dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+#define SG_SO_RUNS(L_, A_)                                                                               \
+    do {                                                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(so_runs<L_, A_>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        hipLaunchKernelGGL((so_runs<L_, A_>), dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, \
+                           (uint32_t)L, (uint64_t)tr.count);                                             \
+    } while (0)
+                if (algo == SMARTGPU_SA) { if (m > 32) SG_SO_RUNS(true, true); else SG_SO_RUNS(false, true); }
+                else { if (m > 32) SG_SO_RUNS(true, false); else SG_SO_RUNS(false, false); }
+#undef SG_SO_RUNS
                 return hipGetLastError();
             }
             const size_t lds = 1040 + (size_t)kSoT * kSoL + 32;

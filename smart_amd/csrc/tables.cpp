@@ -125,4 +125,19 @@ std::vector<uint32_t> bndm_masks(const uint8_t* P, uint32_t m)
     return B;
 }
 
+std::vector<uint32_t> shift_and_masks(const uint8_t* P, uint32_t m)
+{
+    const uint32_t w = std::min<uint32_t>(m, 32);
+    std::vector<uint32_t> S(kSigma, 0u);
+    for (uint32_t i = 0; i < w; ++i) S[P[i]] |= 1u << i;
+    return S;
+}
+
+std::vector<int32_t> quick_search_shifts(const uint8_t* P, uint32_t m)
+{
+    std::vector<int32_t> shift(kSigma, static_cast<int32_t>(m + 1));
+    for (uint32_t i = 0; i < m; ++i) shift[P[i]] = static_cast<int32_t>(m - i);
+    return shift;
+}
+
 }  // namespace sg

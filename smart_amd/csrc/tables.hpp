@@ -40,4 +40,11 @@ std::vector<uint32_t> shift_or_masks(const uint8_t* P, uint32_t m);
 // BNDM: B[c] has bit (w-1-i) set iff P[i]==c, w=min(m,32) (bndm.c:35-40,74-75).
 std::vector<uint32_t> bndm_masks(const uint8_t* P, uint32_t m);
 
+// Shift-And: S[c] has bit i SET iff P[i]==c, over the first w=min(m,32) bytes (sa.c:27-34,72).
+std::vector<uint32_t> shift_and_masks(const uint8_t* P, uint32_t m);
+
+// Quick Search shifts (qs.c:27-31): for the byte c that FOLLOWS the window, m+1 if c does not
+// occur in P, else m minus its right-most position.
+std::vector<int32_t> quick_search_shifts(const uint8_t* P, uint32_t m);
+
 }  // namespace sg

@@ -32,6 +32,7 @@ static int brute_force(const unsigned char *x, int m, const unsigned char *y, in
 }
 
 static int verbose = 1, failures = 0, cases = 0;
+static int min_m = 1; /* shortest pattern the algorithm applies to (raita.c:37: 2); below it -1 is the expected answer */
 static search_fn algo;
 
 static void attempt(int no, const unsigned char *P, int m, const unsigned char *T, int n)
@@ -39,6 +40,7 @@ static void attempt(int no, const unsigned char *P, int m, const unsigned char *
     ++cases;
     int want = brute_force(P, m, T, n);
     int got = algo(P, m, T, n);
+    if (m < min_m) want = -1;
     if (got != want) {
         ++failures;
         if (verbose) printf("\n\tERROR: test failed on case n.%d (m=%d, n=%d)\n\t\tfound %d occ instead of %d\n\n", no, m, n, got, want);
@@ -67,6 +69,10 @@ int main(int argc, char **argv)
         case SMARTGPU_SO: algo = smartgpu_so_search; break;
         case SMARTGPU_BNDM: algo = smartgpu_bndm_search; break;
         case SMARTGPU_EPSM: algo = smartgpu_epsm_search; break;
+        case SMARTGPU_SA: algo = smartgpu_sa_search; break;
+        case SMARTGPU_QS: algo = smartgpu_qs_search; break;
+        case SMARTGPU_TUNEDBM: algo = smartgpu_tunedbm_search; break;
+        case SMARTGPU_RAITA: algo = smartgpu_raita_search; min_m = 2; break;
         default: printf("\tunknown algorithm %s\n", argv[1]); return 1;
     }
     if (smartgpu_device_count() < 1) { fprintf(stderr, "test: no GPU: %s\n", smartgpu_last_error()); return 1; }

@@ -60,6 +60,13 @@ def test_tables_match_oracle(oracle):
         # so.c:56 tests D < lim; the kernel tests bit w-1 — same predicate on any D with bits >= w set
         assert lim == (~(((1 << w) - 1) >> 1)) & 0xFFFFFFFF
         assert np.array_equal(smart_amd.build_table("bndm", P).view(np.uint32), oracle.tables("bndm", P[:w]))
+        # sa.c:27-34: the complement of so.c's masks over the first w bytes
+        assert np.array_equal(smart_amd.build_table("shift_and", P).view(np.uint32), (~S) & np.uint32((1 << w) - 1 if w < 32 else 0xFFFFFFFF))
+        # qs.c:27-31: m+1 for a byte that does not occur, else m - (right-most position)
+        qs = np.full(256, len(P) + 1, dtype=np.int32)
+        for i, c in enumerate(P):
+            qs[c] = len(P) - i
+        assert np.array_equal(smart_amd.build_table("quick_search", P), qs)
 
 
 def test_compute_fails_loudly_without_gpu():

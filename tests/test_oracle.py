@@ -8,7 +8,7 @@ import pytest
 
 from conftest import fuzz_case, load_golden
 
-ALGOS = ("bf", "hor", "bm", "kmp", "so", "bndm", "epsm")
+ALGOS = ("bf", "hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita")
 
 # md5 of the 5,000,000-byte corpora src/textgen.c writes
 TEXTGEN_MD5 = {
@@ -128,6 +128,9 @@ def test_against_reference_builds(oracle):
             mine = oracle.search(a, P, T)
             assert mine == truth, (a, sigma, n, m, k)
             theirs = ref[a].search(P, T)
+            if a == "raita" and m < 2:  # raita.c:37: not applicable
+                assert theirs == -1
+                continue
             if theirs != truth:  # only the documented EPSM tail miss may differ
                 assert a == "epsm" and m % 8 == 0 and m >= 16 and theirs == truth - 1
                 assert np.array_equal(T[n - m:], P)

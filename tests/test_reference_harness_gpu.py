@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 REFBIN = os.path.join(ROOT, "oracle", "_ref", "bin")
 PLUGINS = os.path.join(ROOT, "smart_amd", "bin", "plugins")
-ALGOS = ["hor", "bm", "kmp", "so", "bndm", "epsm"]
+ALGOS = ["hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita"]
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +59,7 @@ def test_reference_smart_binary_reports_ok(smart_tree):
     r = subprocess.run(["./smart", "-text", "rand128", "-plen", "32", "32", "-pset", "3", "-occ", "-pre"],
                        cwd=str(d), env=env, capture_output=True, text=True, timeout=900)
     out = r.stdout
-    assert "Testing 6 algorithms" in out, out + r.stderr
+    assert "Testing %d algorithms" % len(ALGOS) in out, out + r.stderr
     for a in ALGOS:
         line = [ln for ln in out.splitlines() if re.search(r"\] %s \." % a.upper(), ln)]
         assert line and "[OK]" in line[0] and re.search(r"occ [1-9]", line[0]), (a, out)
