@@ -1725,10 +1725,13 @@ hipError_t launch_tiled(K kernel, const ScanArgs& a, TileRange tr, int threads, 
 
 int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 // skip algorithms use the packed matcher up to this m (crossovers measured on 1 GiB rand128
-// with non-temporal tile loads, profiles/r01): HOR 7, BM 8, BNDM 11
+// with non-temporal tile loads, profiles/r01): HOR/TUNEDBM/RAITA 7, BM 8, BNDM 11, QS 14
 static constexpr uint32_t packed_max_m(int algo)
 {
-    return algo == SMARTGPU_HOR ? 7u : algo == SMARTGPU_BM ? 8u : algo == SMARTGPU_BNDM ? 11u : 0u;
+    return (algo == SMARTGPU_HOR || algo == SMARTGPU_TUNEDBM || algo == SMARTGPU_RAITA) ? 7u
+         : algo == SMARTGPU_BM ? 8u : algo == SMARTGPU_BNDM ? 11u
+         : algo == SMARTGPU_QS ? 14u  // three LDS reads per window (text byte, next byte, table): later crossover
+         : 0u;
 }
 
 // tile shapes (threads, bytes per lane)
@@ -1738,7 +1741,7 @@ constexpr int kBndmT = 256, kBndmL = 64;
 constexpr int kSoT = 256, kSoL = 80;
 constexpr int kEpsmT = 256;
 
-static int hor_regime(uint32_t m);
+static int hor_regime(uint32_t m, int algo = SMARTGPU_HOR);
 
 const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
 {
@@ -1750,7 +1753,7 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
             return r == 3 ? "packed_scan" : r == 2 ? "hor_scan_bp" : "hor_scan";
         }
         case SMARTGPU_RAITA:
-        case SMARTGPU_QS: return (pk || hor_regime(m) == 3) ? "packed_scan" : "hor_scan";
+        case SMARTGPU_QS: return (pk || hor_regime(m, algo) == 3) ? "packed_scan" : "hor_scan";
         case SMARTGPU_SA: return "so_runs";
         case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : "kmp_runs";
@@ -1863,13 +1866,13 @@ static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stre
 // (profiles/r01): HOR m=4: flat tile 45 %, bank-private 55 %, packed 74 % of 8 TB/s.
 // Thresholds per algorithm: packed_max_m().
 
-static int hor_regime(uint32_t m)
+static int hor_regime(uint32_t m, int algo)
 {
     const int v = g_tune[0];  // 0 auto, 1 flat, 2 bank-private, 3 packed
     if (v == 3) return 3;
     if (v == 2) return m <= kHaloMax + 1 ? 2 : 1;  // the bank-private kernel keeps whole windows in LDS
     if (v == 1) return 1;
-    return m <= packed_max_m(SMARTGPU_HOR) ? 3 : 1;  // bank-private kernel: only on request
+    return m <= packed_max_m(algo) ? 3 : 1;  // bank-private kernel: only on request
 }
 
 hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream)
@@ -1899,7 +1902,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
         case SMARTGPU_RAITA:
         case SMARTGPU_QS: {  // the Horspool family on hor_scan's tiles; short patterns: packed regime as HOR
             const uint32_t H = a.halo;
-            if ((a.prefer_packed && g_tune[0] == 0) || hor_regime(m) == 3) {
+            if ((a.prefer_packed && g_tune[0] == 0) || hor_regime(m, algo) == 3) {
                 ScanArgs b = a;
                 b.fp_off = kTableOff + 768;
                 return launch_packed<SMARTGPU_HOR>(b, num_cus, stream);
