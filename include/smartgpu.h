@@ -115,6 +115,15 @@ int smartgpu_raita_search(const unsigned char *P, int m, const unsigned char *T,
 /* pre/run times (ms) of the last search on this thread (main.h:34-35 globals) */
 void smartgpu_last_times(double *pre_ms, double *run_ms);
 
+/* ---- occurrence positions (extension) -------------------------- */
+/* The reference only counts (OUTPUT(j) is count++, define.h:33).  This call also returns WHERE:
+ * every s in [off, off+n-m] with T[s..s+m) == P, ascending, relative to text byte 0, through the
+ * packed matcher with an output stage.  positions is a HOST buffer of `cap` entries.
+ * *count always receives the number of occurrences.  Returns SMARTGPU_OK when count <= cap (the
+ * list is complete), SMARTGPU_ERR_NOMEM when it is not (retry with cap >= *count). */
+int smartgpu_find64(const uint8_t *P, uint32_t m, const smartgpu_text *text, uint64_t off, uint64_t n,
+                    uint64_t *positions, uint64_t cap, uint64_t *count);
+
 /* ---- plans: preprocess once, launch many (harness hot loop, smart.c:312-345) ---- */
 /* Builds the algorithm's tables on the host and places them in HBM of `device`. */
 smartgpu_plan *smartgpu_plan_create(int algo, const uint8_t *P, uint32_t m, int device);

@@ -619,6 +619,50 @@ int smartgpu_search64(int algo, const uint8_t* P, uint32_t m, const smartgpu_tex
     return SMARTGPU_OK;
 }
 
+/* ---- occurrence positions ------------------------------------------------- */
+int smartgpu_find64(const uint8_t* P, uint32_t m, const smartgpu_text* text, uint64_t off, uint64_t n,
+                    uint64_t* positions, uint64_t cap, uint64_t* count)
+{
+    const int rc = check_search_args(SMARTGPU_EPSM, P, m, text, off, n);
+    if (rc != SMARTGPU_OK) return rc;
+    if (!count || (cap && !positions)) { set_error("find64: count/positions must not be NULL"); return SMARTGPU_ERR_ARG; }
+    DeviceCtx* d = device_ctx(text->device);
+    if (!d) return SMARTGPU_ERR_HIP;
+    smartgpu_plan* p = smartgpu_plan_create(SMARTGPU_EPSM, P, m, text->device);
+    if (!p) return SMARTGPU_ERR_HIP;
+    unsigned long long* out = nullptr;
+    int r = SMARTGPU_OK;
+    if (cap && hipMalloc(reinterpret_cast<void**>(&out), cap * sizeof(unsigned long long)) != hipSuccess) {
+        set_error("find64: cannot allocate %llu positions on the device", (unsigned long long)cap);
+        r = SMARTGPU_ERR_NOMEM;
+    }
+    unsigned long long total = 0;
+    if (r == SMARTGPU_OK) {
+        sg::ScanArgs a = make_args(p, text, off, n, 0);
+        a.fp_off = sg::kTableOff;  // EPSM blob: the fingerprint follows the pattern slot
+        bool ok = hipMemsetAsync(a.count, 0, sizeof(unsigned long long), d->stream) == hipSuccess &&
+                  sg::launch_find(a, out, cap, d->num_cus, d->stream) == hipSuccess &&
+                  hipMemcpyAsync(d->pinned_count, a.count, sizeof(unsigned long long), hipMemcpyDeviceToHost, d->stream) == hipSuccess &&
+                  hipStreamSynchronize(d->stream) == hipSuccess;
+        if (ok) {
+            total = *d->pinned_count;
+            const unsigned long long have = total < cap ? total : cap;
+            if (have) ok = hipMemcpy(positions, out, have * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess;
+            if (ok && have) std::sort(positions, positions + have);  // waves append in no particular order
+        }
+        if (!ok) {
+            set_error("find64: %s", hipGetErrorString(hipGetLastError()));
+            r = SMARTGPU_ERR_HIP;
+        }
+    }
+    if (out) (void)hipFree(out);
+    smartgpu_plan_free(p);
+    if (r != SMARTGPU_OK) return r;
+    *count = total;
+    if (total > cap) { set_error("find64: %llu occurrences, room for %llu", total, (unsigned long long)cap); return SMARTGPU_ERR_NOMEM; }
+    return SMARTGPU_OK;
+}
+
 void smartgpu_last_times(double* pre_ms, double* run_ms)
 {
     if (pre_ms) *pre_ms = g_last_pre_ms;

@@ -1464,7 +1464,8 @@ struct EpsmFp { uint32_t f0, f1, f2, f3, k0, k1, k2, k3, nd, m; };
 
 // MODE 0: some fingerprint dword is partial (m < 16, m % 4 != 0) -> masked compares;
 // MODE 1: whole dwords only; MODE 2: m > 16, four whole dwords + bytes 16.. verified in memory
-template <int MODE>
+// MASK: return the surviving offsets in `pending` instead of counting them (packed_find)
+template <int MODE, bool MASK = false>
 static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const EpsmFp& fp,
                                                     const uint4& A, const uint4& Bv, uint64_t p0,
                                                     uint32_t& pending, bool overlap_lane)
@@ -1505,7 +1506,7 @@ static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const Eps
         }
     }
 #undef SG_EQ
-    if (MODE == 2) {  // the caller verifies bytes 16.. of the survivors (epsm_verify)
+    if (MODE == 2 || MASK) {  // the caller verifies bytes 16.. of the survivors (epsm_verify) / emits them
         pending = cand;
         return 0;
     }
@@ -1609,6 +1610,62 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_
         }
     }
     flush_hits(hits, a.count);
+}
+
+// Occurrence POSITIONS (an extension: the reference only counts, define.h:33).  The packed
+// matcher with an output stage: the offsets that survive the fingerprint (and, for m > 16, the
+// comparison of bytes 16.. in memory) are appended to `out`.  One atomic per wave and row that
+// has hits: lanes' counts are prefix-summed inside the wave, lane 0 reserves the wave's span of
+// the output.  `out_count` always receives the total; entries past `cap` are dropped.
+template <int THREADS, int MODE>
+__global__ __launch_bounds__(THREADS) void packed_find(ScanArgs a, uint64_t row_first, uint64_t nrows,
+                                                       unsigned long long* out, unsigned long long cap)
+{
+    const uint32_t* fpw = reinterpret_cast<const uint32_t*>(a.blob + a.fp_off);
+    EpsmFp fp;
+    fp.f0 = fpw[0]; fp.f1 = fpw[1]; fp.f2 = fpw[2]; fp.f3 = fpw[3];
+    fp.k0 = fpw[4]; fp.k1 = fpw[5]; fp.k2 = fpw[6]; fp.k3 = fpw[7];
+    fp.m = a.m;
+    fp.nd = (a.m >= 13) ? 4 : (a.m + 3) / 4;
+    constexpr uint32_t ROW_BYTES = THREADS * 16u;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t g = blockIdx.x; g < nrows; g += gridDim.x) {
+        const uint64_t p0 = (row_first + g) * ROW_BYTES + threadIdx.x * 16u;
+        const uint8_t* src = a.text + p0;
+        const uint4 A = ld_stream16(src);
+        const uint4 B = *reinterpret_cast<const uint4*>(src + 16);
+        uint32_t cand = 0;
+        epsm_row<MODE, true>(a, fp, A, B, p0, cand, false);
+        if (MODE == 2) {  // m > 16: bytes 16.. of every survivor
+            uint32_t c = cand;
+            while (c) {
+                const uint32_t k = __builtin_ctz(c);
+                c &= c - 1;
+                if (!global_equal(a.text + p0 + k + 16, a.blob + 16, a.m - 16)) cand &= ~(1u << k);
+            }
+        }
+        if (!__any(cand != 0)) continue;
+        // wave-wide exclusive prefix sum of the lanes' hit counts
+        const uint32_t mine = __popc(cand);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= (uint32_t)d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(a.count, (unsigned long long)total);
+        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+               __builtin_amdgcn_readfirstlane((uint32_t)base);
+        unsigned long long slot = base + (incl - mine);
+        while (cand) {
+            const uint32_t k = __builtin_ctz(cand);
+            cand &= cand - 1;
+            if (slot < cap) out[slot] = p0 + k;
+            ++slot;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1873,6 +1930,29 @@ static int hor_regime(uint32_t m, int algo)
     if (v == 2) return m <= kHaloMax + 1 ? 2 : 1;  // the bank-private kernel keeps whole windows in LDS
     if (v == 1) return 1;
     return m <= packed_max_m(algo) ? 3 : 1;  // bank-private kernel: only on request
+}
+
+// Positions through the packed matcher (any m); a.blob carries the fingerprint at a.fp_off,
+// a.count receives the total number of occurrences.
+hipError_t launch_find(const ScanArgs& a, unsigned long long* out, unsigned long long cap, int num_cus,
+                       hipStream_t stream)
+{
+    if (a.s_end <= a.s_begin) return hipSuccess;
+    const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kEpsmT * 16);
+    if (tr.count == 0) return hipSuccess;
+    uint64_t grid = tr.count;
+    const uint64_t capg = (uint64_t)num_cus * 16;
+    if (grid > capg) grid = capg;
+    if (a.m > 16)
+        hipLaunchKernelGGL((packed_find<kEpsmT, 2>), dim3((uint32_t)grid), dim3(kEpsmT), 0, stream, a, tr.first,
+                           (uint64_t)tr.count, out, cap);
+    else if (a.m % 4 == 0)
+        hipLaunchKernelGGL((packed_find<kEpsmT, 1>), dim3((uint32_t)grid), dim3(kEpsmT), 0, stream, a, tr.first,
+                           (uint64_t)tr.count, out, cap);
+    else
+        hipLaunchKernelGGL((packed_find<kEpsmT, 0>), dim3((uint32_t)grid), dim3(kEpsmT), 0, stream, a, tr.first,
+                           (uint64_t)tr.count, out, cap);
+    return hipGetLastError();
 }
 
 hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream)

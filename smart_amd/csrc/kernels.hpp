@@ -51,6 +51,10 @@ struct LaunchInfo {
 
 // Enqueue the scan for `algo` on `stream`; returns hipSuccess or the launch error.
 hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream);
+// occurrence positions (extension): appends every s in [a.s_begin, a.s_end) with T[s..s+m) == P to `out`
+// (unordered, at most `cap` entries), total in a.count; the blob must be an EPSM blob
+hipError_t launch_find(const ScanArgs& a, unsigned long long* out, unsigned long long cap, int num_cus,
+                       hipStream_t stream);
 const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed);
 
 // tuning knobs (smartgpu_tune): [0] HOR variant 0 auto / 1 flat / 2 bank-private

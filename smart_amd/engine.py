@@ -52,6 +52,7 @@ def lib():
         "smartgpu_text_device": (i32, [vp]),
         "smartgpu_text_read": (i32, [vp, u64, u64, vp]),
         "smartgpu_search64": (i32, [i32, vp, u32, vp, u64, u64, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "smartgpu_find64": (i32, [vp, u32, vp, u64, u64, vp, u64, C.POINTER(u64)]),
         "smartgpu_last_times": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "smartgpu_plan_create": (vp, [i32, vp, u32, i32]),
         "smartgpu_plan_free": (None, [vp]),
@@ -279,6 +280,23 @@ def search(algo, P, text, off=0, n=None):
     if rc != 0:
         raise _err("search64(%s) rc=%d" % (algo, rc))
     return int(c.value), float(pre.value), float(run.value)
+
+
+def find(P, text, off=0, n=None, cap=1 << 20):
+    """(positions, count): the ascending start offsets (relative to text byte 0) of P in
+    text[off..off+n), and their number.  When there are more than `cap`, positions is None and only
+    the count is returned (smartgpu_find64 reports SMARTGPU_ERR_NOMEM; retry with cap >= count)."""
+    P = _u8(P)
+    if n is None:
+        n = len(text) - off
+    out = np.empty(max(cap, 1), dtype=np.uint64)
+    c = C.c_uint64(0)
+    rc = lib().smartgpu_find64(P.ctypes.data, len(P), text._h, off, n, out.ctypes.data, cap, C.byref(c))
+    if rc == -5 and c.value > cap:
+        return None, int(c.value)
+    if rc != 0:
+        raise _err("find64 rc=%d" % rc)
+    return out[:c.value].copy(), int(c.value)
 
 
 def search_host(algo, P, T):

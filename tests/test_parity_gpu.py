@@ -350,3 +350,47 @@ def test_multi_gpu_text_in_one_process(oracle):
     for m in (2, 100, 4000):
         P = ref.pattern(1_000_000 - m // 2, m)  # shard 0/1 boundary is at 1,000,000
         assert mt.search("hor", P, reduce="host")[0] == smart_amd.search("hor", P, ref)[0] >= 1
+
+
+def positions_by_definition(P, T):
+    """Every s with T[s..s+m) == P (bf.c semantics), by numpy."""
+    m, n = len(P), len(T)
+    if m > n:
+        return np.empty(0, dtype=np.uint64)
+    ok = np.ones(n - m + 1, dtype=bool)
+    for i in range(m):
+        ok &= T[i:n - m + 1 + i] == P[i]
+        if not ok.any():
+            break
+    return np.flatnonzero(ok).astype(np.uint64)
+
+
+def test_occurrence_positions(oracle):
+    """smartgpu_find64 (extension): the positions, ascending, equal the
+    definition's; their number equals every counting kernel's."""
+    for sigma, n in ((2, 300000), (4, 300000), (128, 2_000_000)):
+        T = oracle.gen_text(77 + sigma, sigma, 0, n)
+        text = Text.upload(T)
+        for m in (1, 2, 3, 4, 7, 8, 12, 16, 17, 33, 100):
+            P = T[4321:4321 + m]
+            want = positions_by_definition(P, T)
+            pos, cnt = smart_amd.find(P, text, cap=max(len(want), 1))
+            assert cnt == len(want) == smart_amd.search("epsm", P, text)[0], (sigma, m)
+            assert np.array_equal(pos, want), (sigma, m)
+            # a sub-range: positions stay relative to text byte 0
+            off, ln = 1000, 150000
+            sub = want[(want >= off) & (want + m <= off + ln)]
+            pos, cnt = smart_amd.find(P, text, off=off, n=ln, cap=max(len(want), 1))
+            assert cnt == len(sub) and np.array_equal(pos, sub), (sigma, m)
+        text.free()
+    # dense: every offset of a unary text; and a buffer that is too small
+    A = np.full(100000, ord("a"), dtype=np.uint8)
+    text = Text.upload(A)
+    for m in (1, 5, 16, 40):
+        pos, cnt = smart_amd.find(A[:m], text, cap=100000)
+        assert cnt == 100000 - m + 1 and np.array_equal(pos, np.arange(cnt, dtype=np.uint64)), m
+    pos, cnt = smart_amd.find(A[:5], text, cap=10)
+    assert pos is None and cnt == 100000 - 5 + 1
+    pos, cnt = smart_amd.find(b"zz", text, cap=4)
+    assert cnt == 0 and len(pos) == 0
+    text.free()
