@@ -34,6 +34,25 @@ def test_smart_argument_errors_match_reference_messages():
     assert "Unknown algorithm" in run("smart", "-algo", "nope", "-text", "rand2").stdout
 
 
+def test_textgen_reproduces_the_reference_corpora(tmp_path, oracle):
+    """smart_amd/bin/textgen restates src/textgen.c:34-54 without libc's rand(): the eight corpora
+    have the md5 sums of the reference's files and equal the oracle's stream."""
+    import hashlib
+    import numpy as np
+    r = run("textgen", "-data", str(tmp_path / "data"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    md5 = {2: "a8e4cecf43689f3964b4fdfe191aa01b", 4: "c371ad58eda30fa18f35a77b1e775ece",
+           8: "84f8e24bad0787e2caaa250cd0ca715a", 16: "f288f883f5ee611b7667bf25dba9f4c0",
+           32: "743a9837b8172b9e408617b675b97b57", 64: "a89762a4005f7a8c4885d47dcc5da8a1",
+           128: "44ef38efacf46e3705d14f1ed4399faf", 250: "8cf7fb1486e0578f596aa1ac441be246"}
+    for sigma, want in md5.items():
+        d = tmp_path / "data" / ("rand%d" % sigma)
+        blob = (d / ("rand%d.txt" % sigma)).read_bytes()
+        assert len(blob) == 5000000 and hashlib.md5(blob).hexdigest() == want, sigma
+        assert ("#rand%d.txt#" % sigma) in (d / "index.txt").read_text()
+    assert np.array_equal(np.frombuffer(blob[:100000], dtype=np.uint8), oracle.textgen(250, 100000))
+
+
 def test_test_tool_usage():
     assert "usage: ./test ALGONAME" in run("test").stdout
     assert run("test", "nope").returncode == 1
