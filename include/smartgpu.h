@@ -57,7 +57,10 @@ enum {
     SMARTGPU_QS = 7,      /* src/algos/qs.c      Quick Search: shift on the byte after the window */
     SMARTGPU_TUNEDBM = 8, /* src/algos/tunedbm.c Horspool's table with a zero entry + skip loop   */
     SMARTGPU_RAITA = 9,   /* src/algos/raita.c   Horspool's shifts, last/middle/first/rest order; m >= 2 (raita.c:37) */
-    SMARTGPU_NUM_ALGOS = 10
+    SMARTGPU_HASH3 = 10,  /* src/algos/hash3.c   Lecroq: shift under an 8-bit hash of the last 3 bytes; m >= 3 */
+    SMARTGPU_HASH5 = 11,  /* src/algos/hash5.c   ... of the last 5 bytes; m >= 5 */
+    SMARTGPU_HASH8 = 12,  /* src/algos/hash8.c   ... of the last 8 bytes; m >= 8 */
+    SMARTGPU_NUM_ALGOS = 13
 };
 
 typedef struct smartgpu_text smartgpu_text; /* a text resident in one GPU's HBM */
@@ -67,7 +70,7 @@ typedef struct smartgpu_plan smartgpu_plan; /* one (algorithm, pattern) with its
 const char *smartgpu_version(void);
 const char *smartgpu_last_error(void);
 int smartgpu_device_count(void);                   /* <0 on error */
-int smartgpu_algo_id(const char *name);            /* "hor","bm","kmp","so","bndm","epsm","sa","qs","tunedbm","raita" (any case); -1 unknown */
+int smartgpu_algo_id(const char *name);            /* "hor","bm","kmp","so","bndm","epsm","sa","qs","tunedbm","raita","hash3","hash5","hash8" (any case); -1 unknown */
 const char *smartgpu_algo_name(int algo);          /* NULL if out of range */
 int smartgpu_device_sync(int device);              /* waits for the library's stream on `device` */
 
@@ -112,6 +115,9 @@ int smartgpu_sa_search(const unsigned char *P, int m, const unsigned char *T, in
 int smartgpu_qs_search(const unsigned char *P, int m, const unsigned char *T, int n);      /* qs.c:33-52 */
 int smartgpu_tunedbm_search(const unsigned char *P, int m, const unsigned char *T, int n); /* tunedbm.c:36-65 */
 int smartgpu_raita_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* raita.c:35-64; -1 for m < 2 */
+int smartgpu_hash3_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* hash3.c:28-84; -1 for m < 3 */
+int smartgpu_hash5_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* hash5.c; -1 for m < 5 */
+int smartgpu_hash8_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* hash8.c; -1 for m < 8 */
 /* pre/run times (ms) of the last search on this thread (main.h:34-35 globals) */
 void smartgpu_last_times(double *pre_ms, double *run_ms);
 
@@ -197,7 +203,8 @@ int smartgpu_tune(int key, int value);
  *          5 KMP transition table ((m+1)*256, m <= 255): the failure links of kmp.c:27-41
  *            expanded into delta[state][byte]; state m = an occurrence ends here
  *          6 the same over the pattern's own alphabet: k1, colmap[256], table[(m+1)*k1]
- *          7 Shift-And masks S[256] (sa.c:27-34), 8 Quick Search shifts qsBc[256] (qs.c:27-31)   */
+ *          7 Shift-And masks S[256] (sa.c:27-34), 8 Quick Search shifts qsBc[256] (qs.c:27-31),
+ *          13/15/18 HASH3/5/8 shifts[256] followed by the shift after a candidate (hash3.c:36-56)   */
 int smartgpu_build_table(int which, const uint8_t *P, uint32_t m, int32_t *out, uint32_t cap);
 
 #ifdef __cplusplus

@@ -497,6 +497,50 @@ uint64_t oracle_raita(const uint8_t *P, int m, const uint8_t *T, uint64_t n)
     return hits;
 }
 
+/* Lecroq's q-gram hashing (HASHq, q = 3, 5, 8): the shift is looked up under
+ * an 8-bit hash of the window's last q bytes, h = sum y[i-k] * 2^k mod 256;
+ * the hash of the pattern's last q-gram has shift 0 and stops the skip loop,
+ * the window is compared, and moves on by the shift that zero replaced.
+ * reference: src/algos/hash3.c:28-84, hash5.c, hash8.c (they return -1 for
+ * m < q and plant a copy of the pattern after the text as a sentinel; here
+ * the skip loop checks the bound).  For m == q the reference hashes one byte
+ * past the pattern (hash3.c:50 with i = m); this restatement hashes the last
+ * q-gram — the count is the same, every occurrence still stops the loop. */
+static inline uint32_t qgram_hash(const uint8_t *end, int q)
+{
+    uint32_t h = 0;
+    for (int k = q - 1; k >= 0; --k) h = (h << 1) + end[-k];
+    return h & 0xFFu;
+}
+
+static uint64_t hashq(const uint8_t *P, int m, const uint8_t *T, uint64_t n, int q)
+{
+    if (m <= 0 || (uint64_t)m > n) return 0;
+    if (m < q) return oracle_bf(P, m, T, n);  /* "not applicable" in the reference */
+    int32_t shift[256];
+    for (int i = 0; i < 256; ++i) shift[i] = m - q + 1;
+    for (int i = q - 1; i < m - 1; ++i) shift[qgram_hash(P + i, q)] = m - 1 - i;
+    const uint32_t hl = qgram_hash(P + m - 1, q);
+    int32_t after = shift[hl];
+    shift[hl] = 0;
+    if (after == 0) after = 1;
+    uint64_t hits = 0, e = (uint64_t)m - 1;  /* window end */
+    while (e < n) {
+        int32_t sh;
+        while ((sh = shift[qgram_hash(T + e, q)]) != 0) {
+            e += (uint64_t)sh;
+            if (e >= n) return hits;
+        }
+        hits += (memcmp(P, T + e - (uint64_t)(m - 1), (size_t)m) == 0);
+        e += (uint64_t)after;
+    }
+    return hits;
+}
+
+uint64_t oracle_hash3(const uint8_t *P, int m, const uint8_t *T, uint64_t n) { return hashq(P, m, T, n, 3); }
+uint64_t oracle_hash5(const uint8_t *P, int m, const uint8_t *T, uint64_t n) { return hashq(P, m, T, n, 5); }
+uint64_t oracle_hash8(const uint8_t *P, int m, const uint8_t *T, uint64_t n) { return hashq(P, m, T, n, 8); }
+
 /* ------------------------------------------------------------------ */
 /* dispatch                                                            */
 /* ------------------------------------------------------------------ */
@@ -509,6 +553,7 @@ static oracle_fn lookup(const char *name)
         {"kmp", oracle_kmp},   {"so", oracle_so},     {"bndm", oracle_bndm},
         {"epsm", oracle_epsm}, {"sa", oracle_sa},     {"qs", oracle_qs},
         {"tunedbm", oracle_tunedbm}, {"raita", oracle_raita},
+        {"hash3", oracle_hash3}, {"hash5", oracle_hash5}, {"hash8", oracle_hash8},
     };
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i)
         if (strcmp(tab[i].name, name) == 0) return tab[i].fn;

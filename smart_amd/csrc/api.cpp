@@ -121,7 +121,14 @@ struct smartgpu_plan {
 
 namespace {
 
-const char* kAlgoNames[SMARTGPU_NUM_ALGOS] = {"hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita"};
+const char* kAlgoNames[SMARTGPU_NUM_ALGOS] = {"hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita",
+                                              "hash3", "hash5", "hash8"};
+
+// shortest pattern an algorithm applies to (the reference returns -1 below it: raita.c:37, hash3.c:31, ...)
+uint32_t min_pattern(int algo)
+{
+    return algo == SMARTGPU_RAITA ? 2u : algo == SMARTGPU_HASH3 ? 3u : algo == SMARTGPU_HASH5 ? 5u : algo == SMARTGPU_HASH8 ? 8u : 1u;
+}
 
 smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
 {
@@ -262,6 +269,22 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             append(S.data(), 1024);
             break;
         }
+        case SMARTGPU_HASH3:
+        case SMARTGPU_HASH5:
+        case SMARTGPU_HASH8: {  // same layout as HOR: u16 table (zero entry = flag | shift after a candidate)
+            const uint32_t q = algo == SMARTGPU_HASH3 ? 3 : algo == SMARTGPU_HASH5 ? 5 : 8;
+            int32_t after = 1;
+            const std::vector<int32_t> sh = sg::qgram_hash_shifts(P, m, q, &after);
+            std::vector<uint16_t> tab(256);
+            for (int c = 0; c < 256; ++c)
+                tab[c] = sh[c] == 0 ? static_cast<uint16_t>(0x8000u | after) : static_cast<uint16_t>(sh[c]);
+            append(tab.data(), 512);
+            const uint8_t spare[256] = {0};
+            append(spare, 256);
+            append_fingerprint();  // packed regime
+            *prefer_packed = tiny_shifts(sg::bad_char(P, m));
+            break;
+        }
         case SMARTGPU_QS: {  // same layout as HOR: u16 table, 256 spare bytes, fingerprint
             const std::vector<int32_t> qs = sg::quick_search_shifts(P, m);
             std::vector<uint16_t> tab(256);
@@ -282,7 +305,7 @@ int check_search_args(int algo, const uint8_t* P, uint32_t m, const smartgpu_tex
                       uint64_t off, uint64_t n)
 {
     if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS) { set_error("unknown algorithm id %d", algo); return SMARTGPU_ERR_ARG; }
-    if (algo == SMARTGPU_RAITA && m < 2) { set_error("raita: not applicable for m < 2 (raita.c:37)"); return SMARTGPU_NA; }
+    if (m < min_pattern(algo)) { set_error("%s: not applicable for m < %u", kAlgoNames[algo], min_pattern(algo)); return SMARTGPU_NA; }
     if (!P || m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return SMARTGPU_ERR_ARG; }
     if (!text) { set_error("text handle is NULL"); return SMARTGPU_ERR_ARG; }
     if (off > text->n || n > text->n - off) { set_error("range [%llu,+%llu) outside the text (%llu bytes)", (unsigned long long)off, (unsigned long long)n, (unsigned long long)text->n); return SMARTGPU_ERR_ARG; }
@@ -431,7 +454,7 @@ smartgpu_plan* smartgpu_plan_create(int algo, const uint8_t* P, uint32_t m, int 
 {
     if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS) { set_error("unknown algorithm id %d", algo); return nullptr; }
     if (!P || m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return nullptr; }
-    if (algo == SMARTGPU_RAITA && m < 2) { set_error("raita: not applicable for m < 2 (raita.c:37)"); return nullptr; }
+    if (m < min_pattern(algo)) { set_error("%s: not applicable for m < %u", kAlgoNames[algo], min_pattern(algo)); return nullptr; }
     DeviceCtx* d = device_ctx(device);
     if (!d) return nullptr;
     const double t0 = now_ms();
@@ -692,6 +715,9 @@ int smartgpu_sa_search(const unsigned char* P, int m, const unsigned char* T, in
 int smartgpu_qs_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_QS, P, m, T, n); }
 int smartgpu_tunedbm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_TUNEDBM, P, m, T, n); }
 int smartgpu_raita_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_RAITA, P, m, T, n); }
+int smartgpu_hash3_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_HASH3, P, m, T, n); }
+int smartgpu_hash5_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_HASH5, P, m, T, n); }
+int smartgpu_hash8_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_HASH8, P, m, T, n); }
 
 /* ---- one process, several GPUs ------------------------------------------ */
 }  // extern "C"
@@ -813,7 +839,7 @@ int smartgpu_msearch64(int algo, const uint8_t* P, uint32_t m, smartgpu_mtext* t
 {
     if (!text) { set_error("text handle is NULL"); return SMARTGPU_ERR_ARG; }
     if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS) { set_error("unknown algorithm id %d", algo); return SMARTGPU_ERR_ARG; }
-    if (algo == SMARTGPU_RAITA && m < 2) { set_error("raita: not applicable for m < 2 (raita.c:37)"); return SMARTGPU_NA; }
+    if (m < min_pattern(algo)) { set_error("%s: not applicable for m < %u", kAlgoNames[algo], min_pattern(algo)); return SMARTGPU_NA; }
     if (!P || m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return SMARTGPU_ERR_ARG; }
     const int k = static_cast<int>(text->devices.size());
     // preprocessing: the tables are placed on every device
@@ -922,6 +948,14 @@ int smartgpu_build_table(int which, const uint8_t* P, uint32_t m, int32_t* out, 
         }
         case 7: { auto sa = sg::shift_and_masks(P, m); v.assign(sa.begin(), sa.end()); break; }
         case 8: v = sg::quick_search_shifts(P, m); break;
+        case 13: case 15: case 18: {  // HASHq: 256 shifts + the shift after a candidate
+            const uint32_t q = static_cast<uint32_t>(which - 10);
+            if (m < q) { set_error("HASH%u needs m >= %u", q, q); return SMARTGPU_ERR_ARG; }
+            int32_t after = 1;
+            v = sg::qgram_hash_shifts(P, m, q, &after);
+            v.push_back(after);
+            break;
+        }
         default: set_error("unknown table %d", which); return SMARTGPU_ERR_ARG;
     }
     if (v.size() > cap) { set_error("table needs %zu entries, cap %u", v.size(), cap); return SMARTGPU_ERR_ARG; }

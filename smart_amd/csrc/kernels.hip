@@ -161,6 +161,9 @@ __device__ __forceinline__ uint32_t wave_verify(bool has, const uint8_t* tptr,
 //      windows are tested right to left through the halo and completed in memory as in 0
 //   2  Quick Search (qs.c:27-52): the shift comes from the byte AFTER the window, T[s+m]; the
 //      tile carries 16 more bytes at its end for it
+//   3, 5, 8  Lecroq's HASHq (hash3.c:28-84, hash5.c, hash8.c): the table is indexed by an 8-bit hash
+//      of the window's last q = VAR bytes, h = sum T[e-k] * 2^k mod 256; its zero entry (the hash
+//      of the pattern's last q-gram) is the flag, stored with the shift applied after a candidate
 template <int THREADS, int L, bool LONG, int VAR>  // LONG: m-1 > back halo, windows are completed in HBM
 __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_first,
                                                     uint32_t ntiles)
@@ -218,9 +221,17 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
             uint32_t e = (uint32_t)(lo - tile0) + H16;
             const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
             while (e < ehi) {
-                const uint32_t ent = VAR == 2 ? tab[txt[e + 1]] : tab[txt[e]];
+                uint32_t ent;
+                if (VAR >= 3) {
+                    uint32_t h = 0;
+#pragma unroll
+                    for (int q = VAR - 1; q >= 0; --q) h = (h << 1) + txt[e - q];
+                    ent = tab[h & 0xFFu];
+                } else {
+                    ent = VAR == 2 ? tab[txt[e + 1]] : tab[txt[e]];
+                }
                 if (VAR == 2 ? txt[e] == plast : (ent & 0x8000u) != 0) {
-                    uint32_t k = 1;  // bytes matched so far, right to left
+                    uint32_t k = VAR >= 3 ? 0 : 1;  // bytes matched so far, right to left (a hash proves nothing)
                     if (VAR == 1 && !LONG) {  // raita.c:56-57: middle byte, first byte
                         const uint32_t mid = m / 2;
                         if (txt[e - (m - 1) + mid] != ptail[H - (m - 1 - mid)] || txt[e - (m - 1)] != ptail[H - (m - 1)])
@@ -1787,7 +1798,8 @@ static constexpr uint32_t packed_max_m(int algo)
 {
     return (algo == SMARTGPU_HOR || algo == SMARTGPU_TUNEDBM || algo == SMARTGPU_RAITA) ? 7u
          : algo == SMARTGPU_BM ? 8u : algo == SMARTGPU_BNDM ? 11u
-         : algo == SMARTGPU_QS ? 14u  // three LDS reads per window (text byte, next byte, table): later crossover
+         : (algo == SMARTGPU_QS || algo == SMARTGPU_HASH3 || algo == SMARTGPU_HASH5 || algo == SMARTGPU_HASH8)
+               ? 14u  // three or more LDS reads per window: later crossover
          : 0u;
 }
 
@@ -1809,6 +1821,9 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
             const int r = pk ? 3 : hor_regime(m);
             return r == 3 ? "packed_scan" : r == 2 ? "hor_scan_bp" : "hor_scan";
         }
+        case SMARTGPU_HASH3:
+        case SMARTGPU_HASH5:
+        case SMARTGPU_HASH8:
         case SMARTGPU_RAITA:
         case SMARTGPU_QS: return (pk || hor_regime(m, algo) == 3) ? "packed_scan" : "hor_scan";
         case SMARTGPU_SA: return "so_runs";
@@ -1979,6 +1994,9 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 0>, a, tr, kHorT, lds, 8, num_cus, stream);
             return launch_tiled(hor_scan<kHorT, kHorL, false, 0>, a, tr, kHorT, lds, 8, num_cus, stream);
         }
+        case SMARTGPU_HASH3:
+        case SMARTGPU_HASH5:
+        case SMARTGPU_HASH8:
         case SMARTGPU_RAITA:
         case SMARTGPU_QS: {  // the Horspool family on hor_scan's tiles; short patterns: packed regime as HOR
             const uint32_t H = a.halo;
@@ -1989,10 +2007,16 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             }
             const size_t lds = 512 + r16(H + 1) + r16(H) + (size_t)kHorT * kHorL + 16;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
-            if (algo == SMARTGPU_QS) {
-                if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 2>, a, tr, kHorT, lds, 8, num_cus, stream);
-                return launch_tiled(hor_scan<kHorT, kHorL, false, 2>, a, tr, kHorT, lds, 8, num_cus, stream);
-            }
+#define SG_HOR_VAR(V_)                                                                                     \
+    do {                                                                                                  \
+        if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, V_>, a, tr, kHorT, lds, 8, num_cus, stream); \
+        return launch_tiled(hor_scan<kHorT, kHorL, false, V_>, a, tr, kHorT, lds, 8, num_cus, stream);    \
+    } while (0)
+            if (algo == SMARTGPU_QS) SG_HOR_VAR(2);
+            if (algo == SMARTGPU_HASH3) SG_HOR_VAR(3);
+            if (algo == SMARTGPU_HASH5) SG_HOR_VAR(5);
+            if (algo == SMARTGPU_HASH8) SG_HOR_VAR(8);
+#undef SG_HOR_VAR
             if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 1>, a, tr, kHorT, lds, 8, num_cus, stream);
             return launch_tiled(hor_scan<kHorT, kHorL, false, 1>, a, tr, kHorT, lds, 8, num_cus, stream);
         }

@@ -140,4 +140,19 @@ std::vector<int32_t> quick_search_shifts(const uint8_t* P, uint32_t m)
     return shift;
 }
 
+std::vector<int32_t> qgram_hash_shifts(const uint8_t* P, uint32_t m, uint32_t q, int32_t* after)
+{
+    auto hash = [&](uint32_t end) {  // q-gram ending at P[end]
+        uint32_t h = 0;
+        for (uint32_t k = 0; k < q; ++k) h = (h << 1) + P[end + 1 - q + k];
+        return h & 0xFFu;
+    };
+    std::vector<int32_t> shift(kSigma, static_cast<int32_t>(m - q + 1));
+    for (uint32_t i = q - 1; i + 1 < m; ++i) shift[hash(i)] = static_cast<int32_t>(m - 1 - i);
+    const uint32_t hl = hash(m - 1);
+    *after = shift[hl] == 0 ? 1 : shift[hl];
+    shift[hl] = 0;
+    return shift;
+}
+
 }  // namespace sg

@@ -47,4 +47,9 @@ std::vector<uint32_t> shift_and_masks(const uint8_t* P, uint32_t m);
 // occur in P, else m minus its right-most position.
 std::vector<int32_t> quick_search_shifts(const uint8_t* P, uint32_t m);
 
+// HASHq (hash3.c:36-56, hash5.c, hash8.c): shift[h] for the 8-bit hash h = sum y[i-k]*2^k mod 256 of the
+// window's last q bytes; the hash of the pattern's last q-gram gets 0 and `*after` the shift it
+// replaced (at least 1).  m >= q.
+std::vector<int32_t> qgram_hash_shifts(const uint8_t* P, uint32_t m, uint32_t q, int32_t* after);
+
 }  // namespace sg

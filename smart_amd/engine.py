@@ -15,7 +15,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SMARTGPU_LIB overrides the library path (A/B runs of two builds in one session)
 LIB_PATH = os.environ.get("SMARTGPU_LIB") or os.path.join(_HERE, "csrc", "libsmartgpu.so")
-ALGOS = ("hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita")
+ALGOS = ("hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8")
+# shortest pattern each algorithm applies to (the reference returns -1 below: raita.c:37, hash3.c:31, ...)
+MIN_M = {"raita": 2, "hash3": 3, "hash5": 5, "hash8": 8}
 
 _lib = None
 
@@ -339,7 +341,7 @@ def tune(key, value):
 def build_table(which, P):
     P = _u8(P)
     names = {"bad_char": 0, "good_suffix": 1, "kmp_next": 2, "shift_or": 3, "bndm": 4, "kmp_dfa": 5,
-             "kmp_dfa_compressed": 6, "shift_and": 7, "quick_search": 8}
+             "kmp_dfa_compressed": 6, "shift_and": 7, "quick_search": 8, "hash3": 13, "hash5": 15, "hash8": 18}
     out = np.empty(max(256, len(P) + 1, (len(P) + 1) * 256 + 257 if which.startswith("kmp_dfa") else 0), dtype=np.int32)
     k = lib().smartgpu_build_table(names[which], P.ctypes.data, len(P), out.ctypes.data, len(out))
     if k < 0:

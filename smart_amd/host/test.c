@@ -73,6 +73,9 @@ int main(int argc, char **argv)
         case SMARTGPU_QS: algo = smartgpu_qs_search; break;
         case SMARTGPU_TUNEDBM: algo = smartgpu_tunedbm_search; break;
         case SMARTGPU_RAITA: algo = smartgpu_raita_search; min_m = 2; break;
+        case SMARTGPU_HASH3: algo = smartgpu_hash3_search; min_m = 3; break;
+        case SMARTGPU_HASH5: algo = smartgpu_hash5_search; min_m = 5; break;
+        case SMARTGPU_HASH8: algo = smartgpu_hash8_search; min_m = 8; break;
         default: printf("\tunknown algorithm %s\n", argv[1]); return 1;
     }
     if (smartgpu_device_count() < 1) { fprintf(stderr, "test: no GPU: %s\n", smartgpu_last_error()); return 1; }
