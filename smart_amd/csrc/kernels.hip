@@ -1793,13 +1793,15 @@ hipError_t launch_tiled(K kernel, const ScanArgs& a, TileRange tr, int threads, 
 
 int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 // skip algorithms use the packed matcher up to this m (crossovers measured on 1 GiB rand128
-// with non-temporal tile loads, profiles/r01): HOR/TUNEDBM/RAITA 7, BM 8, BNDM 11, QS 14
+// with non-temporal tile loads, profiles/r01): HOR/TUNEDBM/RAITA 7, BM 8, BNDM 11, QS 14, HASH3/5/8 32/64/28
 static constexpr uint32_t packed_max_m(int algo)
 {
     return (algo == SMARTGPU_HOR || algo == SMARTGPU_TUNEDBM || algo == SMARTGPU_RAITA) ? 7u
          : algo == SMARTGPU_BM ? 8u : algo == SMARTGPU_BNDM ? 11u
-         : (algo == SMARTGPU_QS || algo == SMARTGPU_HASH3 || algo == SMARTGPU_HASH5 || algo == SMARTGPU_HASH8)
-               ? 14u  // three or more LDS reads per window: later crossover
+         : algo == SMARTGPU_QS ? 14u     // three LDS reads per window (text byte, next byte, table): later crossover
+         : algo == SMARTGPU_HASH3 ? 32u  // q text reads + hash + table per window, shifts of at most m-q+1:
+         : algo == SMARTGPU_HASH5 ? 64u  //   the tiles pass the packed matcher's 78 % only here
+         : algo == SMARTGPU_HASH8 ? 28u  //   (profiles/r01/n_sweep_hash_mid.log)
          : 0u;
 }
 
