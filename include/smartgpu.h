@@ -187,10 +187,16 @@ void *smartgpu_stream_handle(int device);               /* hipStream_t of the li
  * the scan kernels are compared with besides the 8 TB/s spec peak. */
 int smartgpu_probe_read_ms(const smartgpu_text *t, int reps, double *ms_per_pass);
 
-/* Kernel-variant selection for experiments and A/B measurements (not needed in
- * normal use): key 0 = regime of the skip algorithms, 0 auto / 1 always the LDS-tile
- * skip loop / 2 Horspool bank-private LDS layout / 3 packed matcher; key 2 = rows in
- * flight of the packed matcher (1, 2, 4). */
+/* Kernel-variant selection for experiments and A/B measurements (not needed in normal use;
+ * every variant is parity-tested).  Keys:
+ *   0  regime of the skip algorithms: 0 auto / 1 always the LDS-tile skip loop / 2 Horspool's
+ *      bank-private LDS layout / 3 always the packed matcher
+ *   3  KMP: 0 kmp_runs (transition table) / 1 kmp_scan (LDS tiles, m <= 40) / 2 kmp_links_runs
+ *      (failure links followed per byte)
+ *   5  run length in bytes of the runs kernels (so_runs, kmp_runs); 0 = default
+ *   6  SO: 0 so_runs (bank-private table, line fetch) / 1 so_scan (LDS tiles) / 2 so_runs64
+ *      (shared table, 64-byte steps)
+ *   7  packed matcher load policy: 0 A non-temporal + B cached / 1 both cached / 3 one load + shuffle */
 int smartgpu_tune(int key, int value);
 
 /* Host-side preprocessing exposed for tests (same tables the kernels stage in

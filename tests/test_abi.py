@@ -67,6 +67,19 @@ def test_tables_match_oracle(oracle):
         for i, c in enumerate(P):
             qs[c] = len(P) - i
         assert np.array_equal(smart_amd.build_table("quick_search", P), qs)
+        # hash3.c:36-56 (and hash5.c, hash8.c): shifts under the 8-bit q-gram hash, then the shift after a candidate
+        for q in (3, 5, 8):
+            if len(P) < q:
+                continue
+            m = len(P)
+            h = lambda end: sum(int(P[end - k]) << k for k in range(q)) & 0xFF  # noqa: E731
+            sh = np.full(256, m - q + 1, dtype=np.int32)
+            for i in range(q - 1, m - 1):
+                sh[h(i)] = m - 1 - i
+            after = max(int(sh[h(m - 1)]), 1)
+            sh[h(m - 1)] = 0
+            got = smart_amd.build_table("hash%d" % q, P)
+            assert np.array_equal(got[:256], sh) and got[256] == after, (q, m)
 
 
 def test_compute_fails_loudly_without_gpu():
@@ -126,6 +139,13 @@ int main() {
                 sink += sg::kmp_next(P.data(), m)[m];
                 sink += sg::shift_or_masks(P.data(), m)[P[0]];
                 sink += sg::bndm_masks(P.data(), m)[P[0]];
+                sink += sg::shift_and_masks(P.data(), m)[P[0]];
+                sink += sg::quick_search_shifts(P.data(), m)[P[0]];
+                for (unsigned q : {3u, 5u, 8u})
+                    if (m >= q) {
+                        int32_t after = 0;
+                        sink += sg::qgram_hash_shifts(P.data(), m, q, &after)[P[m - 1]] + after;
+                    }
                 if (m <= 255) {
                     uint32_t k1 = 0;
                     sink += sg::kmp_dfa(P.data(), m)[m * 256u + P[0]];
