@@ -59,8 +59,8 @@ def load_traffic(kernel, workload_key):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--algo", default="hor")
     ap.add_argument("--plen", dest="m", type=int, default=32, help="pattern length m")
     ap.add_argument("--sigma", type=int, default=128)

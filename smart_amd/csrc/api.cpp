@@ -106,7 +106,7 @@ struct smartgpu_plan {
     uint32_t m = 0;
     uint32_t halo = 0;
     uint32_t prefer_packed = 0;  // see build_blob
-    uint32_t kmp_k1 = 0;         // see build_blob
+    uint32_t sparse = 0;         // see build_blob
     uint8_t* blob = nullptr;               // device: pattern + tables
     unsigned long long* results = nullptr; // device: kResultSlots counters (library-owned)
     unsigned long long* ext_results = nullptr; // caller-owned device buffer, if set
@@ -157,10 +157,10 @@ smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
 
 // Build the device blob (pattern + tables) for (algo, P, m) in a host vector.
 std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t* halo,
-                                uint32_t* prefer_packed, uint32_t* kmp_k1)
+                                uint32_t* prefer_packed, uint32_t* sparse)
 {
     *prefer_packed = 0;
-    *kmp_k1 = 0;
+    *sparse = 0;
     std::vector<uint8_t> blob(sg::kPatternBytes, 0);
     std::memcpy(blob.data(), P, m);
     auto append = [&blob](const void* p, size_t bytes) {
@@ -190,6 +190,20 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         const double e = static_cast<double>(sum) / m;
         return m > 7 && e < std::min(0.4 * m, 12.0);
     };
+    // The opposite case: hardly any symbol of the pattern repeats (random text over a large
+    // alphabet).  Windows then die on their first comparison and a skip kernel only streams; it
+    // runs best with FEWER workgroups per CU (kTileWgs in kernels.hip, measured).  Natural
+    // language and small alphabets repeat symbols and keep the lanes busy verifying: more
+    // workgroups hide that.  The count does not depend on the choice.
+    {
+        uint32_t distinct = 0;
+        bool seen[256] = {false};
+        for (uint32_t i = 0; i < m; ++i)
+            if (!seen[P[i]]) { seen[P[i]] = true; ++distinct; }
+        // >= 80 % of the min(m,64) possible, and windows long enough for long shifts (m = 8: 61 % with
+        // four workgroups per CU against 75 % with eight)
+        *sparse = m >= 16 && distinct * 10 >= std::min<uint32_t>(m, 64) * 8;
+    }
     *halo = std::min<uint32_t>(m - 1, sg::kHaloMax);
     switch (algo) {
         case SMARTGPU_TUNEDBM:  // tunedbm.c:38-40: the same table with a zero for P[m-1] — the flag bit below
@@ -323,7 +337,7 @@ sg::ScanArgs make_args(const smartgpu_plan* p, const smartgpu_text* text, uint64
     a.halo = p->halo;
     a.fp_off = 0;
     a.prefer_packed = p->prefer_packed;
-    a.kmp_k1 = p->kmp_k1;
+    a.sparse = p->sparse;
     a.blob = p->blob;
     a.count = p->slot_ptr(slot);
     return a;
@@ -462,7 +476,7 @@ smartgpu_plan* smartgpu_plan_create(int algo, const uint8_t* P, uint32_t m, int 
     p->device = device;
     p->algo = algo;
     p->m = m;
-    const std::vector<uint8_t> blob = build_blob(algo, P, m, &p->halo, &p->prefer_packed, &p->kmp_k1);
+    const std::vector<uint8_t> blob = build_blob(algo, P, m, &p->halo, &p->prefer_packed, &p->sparse);
     bool ok = hipMalloc(reinterpret_cast<void**>(&p->blob), blob.size()) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&p->results), sizeof(unsigned long long) * sg::kResultSlots) == hipSuccess;
     if (ok) {

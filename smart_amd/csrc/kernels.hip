@@ -1778,11 +1778,20 @@ TileRange tiles_for(uint64_t lo, uint64_t hi, uint64_t tb)
 
 uint32_t r16(uint32_t x) { return (x + 15u) & ~15u; }
 
+// Workgroups per CU of the LDS-tile skip kernels.  FOUR (64 KB of tiles in flight per CU), not
+// the eight or nine the LDS would hold, when the pattern promises a pure streaming scan
+// (a.sparse, api.cpp): measured on 1, 1.37 and 4 GiB of rand128, HOR m=32 runs at 85-87 % of
+// 8 TB/s with 4, 78-82 % with 8, 75 % with 6, 82 % with 16 (two rounds) — profiles/r01/
+// o_wgs_per_cu.log; BM and BNDM follow the same curve.  Where lanes spend their time verifying
+// (English text: HOR m=64 47 % with 8, 40 % with 4) the extra waves pay: EIGHT.
+static int tile_wgs(const ScanArgs& a) { return a.sparse ? 4 : 8; }
+
 template <typename K>
 hipError_t launch_tiled(K kernel, const ScanArgs& a, TileRange tr, int threads, size_t lds,
                         int wgs_per_cu, int num_cus, hipStream_t stream)
 {
     if (tr.count == 0) return hipSuccess;
+    if (g_tune[4]) wgs_per_cu = g_tune[4];  // A/B: workgroups per CU of the tile kernels
     uint32_t grid = (uint32_t)num_cus * (uint32_t)wgs_per_cu;
     if (grid > tr.count) grid = tr.count;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a, tr.first, tr.count);
@@ -1914,7 +1923,9 @@ static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stre
     if (tr.count == 0) return hipSuccess;
     const int rows = 4;  // rows in flight per workgroup step (1 and 2 measured slower, profiles/r01)
     uint64_t grid = ((uint64_t)tr.count + rows - 1) / rows;
-    const uint64_t cap = (uint64_t)num_cus * 8;
+    // (32 workgroups per CU measured 77-82 % against 75-77 % on sparse hits, but every wave with hits
+    // ends in an atomic on the result slot and same-address atomics serialise: 34 % on dense hits)
+    const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 8);
     if (grid > cap) grid = cap;
 #define SG_PACKED(M_, P_)                                                                           \
     hipLaunchKernelGGL((packed_scan<kEpsmT, 4, ALGO, M_, P_>), dim3((uint32_t)grid), dim3(kEpsmT), 0,   \
@@ -1993,8 +2004,8 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             }
             const size_t lds = 512 + r16(H + 1) + r16(H) + (size_t)kHorT * kHorL;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
-            if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 0>, a, tr, kHorT, lds, 8, num_cus, stream);
-            return launch_tiled(hor_scan<kHorT, kHorL, false, 0>, a, tr, kHorT, lds, 8, num_cus, stream);
+            if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 0>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);
+            return launch_tiled(hor_scan<kHorT, kHorL, false, 0>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);
         }
         case SMARTGPU_HASH3:
         case SMARTGPU_HASH5:
@@ -2011,16 +2022,16 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
 #define SG_HOR_VAR(V_)                                                                                     \
     do {                                                                                                  \
-        if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, V_>, a, tr, kHorT, lds, 8, num_cus, stream); \
-        return launch_tiled(hor_scan<kHorT, kHorL, false, V_>, a, tr, kHorT, lds, 8, num_cus, stream);    \
+        if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, V_>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream); \
+        return launch_tiled(hor_scan<kHorT, kHorL, false, V_>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);    \
     } while (0)
             if (algo == SMARTGPU_QS) SG_HOR_VAR(2);
             if (algo == SMARTGPU_HASH3) SG_HOR_VAR(3);
             if (algo == SMARTGPU_HASH5) SG_HOR_VAR(5);
             if (algo == SMARTGPU_HASH8) SG_HOR_VAR(8);
 #undef SG_HOR_VAR
-            if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 1>, a, tr, kHorT, lds, 8, num_cus, stream);
-            return launch_tiled(hor_scan<kHorT, kHorL, false, 1>, a, tr, kHorT, lds, 8, num_cus, stream);
+            if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 1>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);
+            return launch_tiled(hor_scan<kHorT, kHorL, false, 1>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);
         }
         case SMARTGPU_BM: {
             if ((m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
@@ -2031,7 +2042,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             const uint32_t H = a.halo;
             const size_t lds = 1024 + r16(2 * (m + 1)) + r16(H + 1) + r16(H) + (size_t)kBmT * kBmL;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmT * kBmL);
-            const int wgs = g_tune[4] ? g_tune[4] : (lds <= 20 * 1024 ? 8 : 6);  // workgroups per CU by LDS footprint
+            const int wgs = tile_wgs(a);
             if (m - 1 > H) return launch_tiled(bm_scan<kBmT, kBmL, true>, a, tr, kBmT, lds, wgs, num_cus, stream);
             return launch_tiled(bm_scan<kBmT, kBmL, false>, a, tr, kBmT, lds, wgs, num_cus, stream);
         }
@@ -2044,8 +2055,8 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             const uint32_t w = m < 32 ? m : 32;
             const size_t lds = 1024 + 32 + (size_t)kBndmT * kBndmL;
             const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
-            if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true>, a, tr, kBndmT, lds, 8, num_cus, stream);
-            return launch_tiled(bndm_scan<kBndmT, kBndmL, false>, a, tr, kBndmT, lds, 8, num_cus, stream);
+            if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
+            return launch_tiled(bndm_scan<kBndmT, kBndmL, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
         }
         case SMARTGPU_SA:  // Shift-And: so_runs<.., AND = true>; the A/B kernels below are Shift-Or only
         case SMARTGPU_SO: {

@@ -30,7 +30,8 @@ struct ScanArgs {
     uint32_t halo;              // skip kernels: back-halo H = min(m-1, kHaloMax); serial: forward halo
     uint32_t fp_off;            // packed kernel: blob offset of the fingerprint (set by launch_scan)
     uint32_t prefer_packed;     // HOR/BM: the shift tables promise tiny shifts (small alphabet) -> packed regime
-    uint32_t kmp_k1;            // unused (was: row stride of a compressed KMP table)
+    uint32_t sparse;            // skip kernels: the pattern's own symbols promise long shifts and few candidates
+                                // (api.cpp build_blob) -> fewer workgroups per CU, see kTileWgs
     const uint8_t* blob;        // device: [pattern kPatternBytes][tables ...]
     unsigned long long* count;  // device result slot (pre-zeroed)
 };

@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--gib", type=float, default=1.0)
     ap.add_argument("--sigma", type=int, default=128)
     ap.add_argument("--ms", default="4,8,32,256")
-    ap.add_argument("--algos", default=",".join(smart_amd.ALGOS))
+    ap.add_argument("--algos", default=",".join(smart_amd.ALGOS[:6]), help="default: the six hot-path algorithms")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--json", default=None)
     ap.add_argument("--tune", default="", help="comma list key=value passed to smartgpu_tune")
@@ -53,6 +53,8 @@ def main():
             pats.append(text.pattern(k, m))
         ref_counts = None
         for algo in args.algos.split(","):
+            if m < smart_amd.MIN_M.get(algo, 1):  # the algorithm does not apply (raita.c:37, hash3.c:31, ...)
+                continue
             plans = [Plan(algo, p) for p in pats]
             plans[0].launch(text, slot=1)  # warm-up
             plans[0].result(1)
