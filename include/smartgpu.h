@@ -60,7 +60,8 @@ enum {
     SMARTGPU_HASH3 = 10,  /* src/algos/hash3.c   Lecroq: shift under an 8-bit hash of the last 3 bytes; m >= 3 */
     SMARTGPU_HASH5 = 11,  /* src/algos/hash5.c   ... of the last 5 bytes; m >= 5 */
     SMARTGPU_HASH8 = 12,  /* src/algos/hash8.c   ... of the last 8 bytes; m >= 8 */
-    SMARTGPU_NUM_ALGOS = 13
+    SMARTGPU_SBNDM = 13,  /* src/algos/sbndm.c   Simplified BNDM; m >= 2 */
+    SMARTGPU_NUM_ALGOS = 14
 };
 
 typedef struct smartgpu_text smartgpu_text; /* a text resident in one GPU's HBM */
@@ -70,7 +71,7 @@ typedef struct smartgpu_plan smartgpu_plan; /* one (algorithm, pattern) with its
 const char *smartgpu_version(void);
 const char *smartgpu_last_error(void);
 int smartgpu_device_count(void);                   /* <0 on error */
-int smartgpu_algo_id(const char *name);            /* "hor","bm","kmp","so","bndm","epsm","sa","qs","tunedbm","raita","hash3","hash5","hash8" (any case); -1 unknown */
+int smartgpu_algo_id(const char *name);            /* "hor","bm","kmp","so","bndm","epsm","sa","qs","tunedbm","raita","hash3","hash5","hash8","sbndm" (any case); -1 unknown */
 const char *smartgpu_algo_name(int algo);          /* NULL if out of range */
 int smartgpu_device_sync(int device);              /* waits for the library's stream on `device` */
 
@@ -118,6 +119,7 @@ int smartgpu_raita_search(const unsigned char *P, int m, const unsigned char *T,
 int smartgpu_hash3_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* hash3.c:28-84; -1 for m < 3 */
 int smartgpu_hash5_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* hash5.c; -1 for m < 5 */
 int smartgpu_hash8_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* hash8.c; -1 for m < 8 */
+int smartgpu_sbndm_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* sbndm.c:28-149; -1 for m < 2 */
 /* pre/run times (ms) of the last search on this thread (main.h:34-35 globals) */
 void smartgpu_last_times(double *pre_ms, double *run_ms);
 

@@ -541,6 +541,53 @@ uint64_t oracle_hash3(const uint8_t *P, int m, const uint8_t *T, uint64_t n) { r
 uint64_t oracle_hash5(const uint8_t *P, int m, const uint8_t *T, uint64_t n) { return hashq(P, m, T, n, 5); }
 uint64_t oracle_hash8(const uint8_t *P, int m, const uint8_t *T, uint64_t n) { return hashq(P, m, T, n, 8); }
 
+/* Simplified BNDM: the window is read right to left through the same
+ * masks as BNDM, two bytes before the first test and no bookkeeping of
+ * the longest prefix seen; a mismatch after k more bytes moves the window
+ * past the failing byte, an occurrence moves it by the period of the
+ * (32-byte prefix of the) pattern.  reference: src/algos/sbndm.c:28-83,
+ * search_large (m > 32: prefix + verification, with a leading skip loop on
+ * B[c] == 0) sbndm.c:91-149; -1 for m < 2 (:36) — here brute force. */
+uint64_t oracle_sbndm(const uint8_t *P, int m, const uint8_t *T, uint64_t n)
+{
+    if (m <= 0 || (uint64_t)m > n) return 0;
+    if (m < 2) return oracle_bf(P, m, T, n);
+    const int w = m < 32 ? m : 32;
+    uint32_t B[ORACLE_SIGMA];
+    memset(B, 0, sizeof B);
+    for (int p = 0; p < w; ++p) B[P[p]] |= 1u << (31 - p);
+    /* period of P[0..w): w minus its longest proper border */
+    int32_t border[33];
+    border[0] = -1;
+    for (int i = 0, b = -1; i < w; ++i) {
+        while (b >= 0 && P[i] != P[b]) b = border[b];
+        border[i + 1] = ++b;
+    }
+    const uint64_t period = (uint64_t)(w - border[w]);
+    uint64_t hits = 0, e = (uint64_t)w - 1;  /* end of the w-byte window */
+    const uint64_t e_last = n - (uint64_t)m + (uint64_t)w - 1;
+    while (e <= e_last) {
+        uint32_t D = B[T[e]];
+        if (m > 32 && D == 0) { e += (uint64_t)w; continue; }  /* sbndm.c:133 */
+        int k = 1;
+        for (;;) {
+            D = (D << 1) & B[T[e - (uint64_t)k]];
+            if (k == w - 1 || D == 0) break;
+            ++k;
+        }
+        if (D != 0) {
+            const uint64_t s = e + 1 - (uint64_t)w;
+            int q = w;
+            while (q < m && P[q] == T[s + (uint64_t)q]) ++q;
+            hits += (q == m);
+            e += period;
+        } else {
+            e += (uint64_t)(w - k);
+        }
+    }
+    return hits;
+}
+
 /* ------------------------------------------------------------------ */
 /* dispatch                                                            */
 /* ------------------------------------------------------------------ */
@@ -554,6 +601,7 @@ static oracle_fn lookup(const char *name)
         {"epsm", oracle_epsm}, {"sa", oracle_sa},     {"qs", oracle_qs},
         {"tunedbm", oracle_tunedbm}, {"raita", oracle_raita},
         {"hash3", oracle_hash3}, {"hash5", oracle_hash5}, {"hash8", oracle_hash8},
+        {"sbndm", oracle_sbndm},
     };
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i)
         if (strcmp(tab[i].name, name) == 0) return tab[i].fn;

@@ -122,12 +122,12 @@ struct smartgpu_plan {
 namespace {
 
 const char* kAlgoNames[SMARTGPU_NUM_ALGOS] = {"hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita",
-                                              "hash3", "hash5", "hash8"};
+                                              "hash3", "hash5", "hash8", "sbndm"};
 
 // shortest pattern an algorithm applies to (the reference returns -1 below it: raita.c:37, hash3.c:31, ...)
 uint32_t min_pattern(int algo)
 {
-    return algo == SMARTGPU_RAITA ? 2u : algo == SMARTGPU_HASH3 ? 3u : algo == SMARTGPU_HASH5 ? 5u : algo == SMARTGPU_HASH8 ? 8u : 1u;
+    return (algo == SMARTGPU_RAITA || algo == SMARTGPU_SBNDM) ? 2u : algo == SMARTGPU_HASH3 ? 3u : algo == SMARTGPU_HASH5 ? 5u : algo == SMARTGPU_HASH8 ? 8u : 1u;
 }
 
 smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
@@ -268,10 +268,17 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             append(S.data(), 1024);
             break;
         }
+        case SMARTGPU_SBNDM:
         case SMARTGPU_BNDM: {
             const std::vector<uint32_t> B = sg::bndm_masks(P, m);
             append(B.data(), 1024);
             append_fingerprint();  // packed regime
+            if (algo == SMARTGPU_SBNDM) {  // sbndm.c:44-55: the shift after an occurrence = period of P[0..w)
+                const uint32_t w = std::min<uint32_t>(m, 32);
+                const std::vector<int32_t> nx = sg::kmp_next(P, w);  // nx[w] = longest proper border of the prefix
+                const uint32_t period = w - static_cast<uint32_t>(nx[w]);
+                append(&period, 4);
+            }
             *prefer_packed = tiny_shifts(sg::bad_char(P, m));
             break;
         }
@@ -732,6 +739,7 @@ int smartgpu_raita_search(const unsigned char* P, int m, const unsigned char* T,
 int smartgpu_hash3_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_HASH3, P, m, T, n); }
 int smartgpu_hash5_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_HASH5, P, m, T, n); }
 int smartgpu_hash8_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_HASH8, P, m, T, n); }
+int smartgpu_sbndm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_SBNDM, P, m, T, n); }
 
 /* ---- one process, several GPUs ------------------------------------------ */
 }  // extern "C"

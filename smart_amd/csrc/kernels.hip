@@ -502,7 +502,11 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
 // w = min(m,32); tiles are indexed by the END of the w-byte (prefix) window.
 // LDS: u32 B[256] | text [tile0-32, tile0+TB)
 // ---------------------------------------------------------------------------
-template <int THREADS, int L, bool LONG>  // LONG: m > 32, prefix hits are verified
+// SIMPLE = true: Simplified BNDM (sbndm.c:28-149) on the same tiles and masks: no bookkeeping of the
+// longest prefix seen — a window that dies after k more bytes moves past the failing byte (shift
+// w-k), an occurrence moves by the period of the (prefix of the) pattern, which the host stores
+// after the fingerprint.
+template <int THREADS, int L, bool LONG, bool SIMPLE>  // LONG: m > 32, prefix hits are verified
 __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_first,
                                                      uint32_t ntiles)
 {
@@ -518,6 +522,7 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
     for (uint32_t i = threadIdx.x; i < 256; i += THREADS)
         B[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] << (32 - w);
 
+    const uint32_t period = SIMPLE ? *reinterpret_cast<const uint32_t*>(a.blob + kTableOff + 1024 + 32) : 0u;
     const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
     uint32_t hits = 0;
     static_assert(TB == THREADS * 64, "prefetch registers are written out for L = 64");
@@ -560,7 +565,34 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
                 // not occur in the prefix) moves the window by w after one text and one table read
                 uint32_t D = B[txt[e]];
                 if (D == 0) {
-                    e += w;
+                    // sbndm.c:60-63 reads a second byte before it tests D and so moves by w-1
+                    // here; its long-pattern form skips by w like BNDM (sbndm.c:133)
+                    e += (SIMPLE && !LONG) ? w - 1 : w;
+                    continue;
+                }
+                if (SIMPLE) {
+                    uint32_t k = 1;
+                    for (;;) {  // sbndm.c:61-65
+                        D = (D << 1) & B[txt[e - k]];
+                        if (k == w - 1 || D == 0) break;
+                        ++k;
+                    }
+                    if (D != 0) {  // the whole window matched
+                        if (!LONG) {
+                            ++hits;
+                        } else {
+                            const uint8_t* rest = a.text + tile0 + (e - H16) + 1;  // = text + s + w
+                            if (!parked) {
+                                parked = true;
+                                parked_at = rest;
+                            } else {
+                                hits += global_equal(rest, a.blob + w, m - w);
+                            }
+                        }
+                        e += period;
+                    } else {
+                        e += w - k;
+                    }
                     continue;
                 }
                 int i = (int)w - 2;  // bytes still to read, minus one
@@ -1841,6 +1873,7 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
         case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : "kmp_runs";
         case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : "so_runs";
+        case SMARTGPU_SBNDM:
         case SMARTGPU_BNDM: return (pk || (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1)) ? "packed_scan" : "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
     }
@@ -2046,6 +2079,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             if (m - 1 > H) return launch_tiled(bm_scan<kBmT, kBmL, true>, a, tr, kBmT, lds, wgs, num_cus, stream);
             return launch_tiled(bm_scan<kBmT, kBmL, false>, a, tr, kBmT, lds, wgs, num_cus, stream);
         }
+        case SMARTGPU_SBNDM:
         case SMARTGPU_BNDM: {
             if ((m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
                 ScanArgs b = a;
@@ -2055,8 +2089,12 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             const uint32_t w = m < 32 ? m : 32;
             const size_t lds = 1024 + 32 + (size_t)kBndmT * kBndmL;
             const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
-            if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
-            return launch_tiled(bndm_scan<kBndmT, kBndmL, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
+            if (algo == SMARTGPU_SBNDM) {
+                if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
+                return launch_tiled(bndm_scan<kBndmT, kBndmL, false, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
+            }
+            if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
+            return launch_tiled(bndm_scan<kBndmT, kBndmL, false, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
         }
         case SMARTGPU_SA:  // Shift-And: so_runs<.., AND = true>; the A/B kernels below are Shift-Or only
         case SMARTGPU_SO: {

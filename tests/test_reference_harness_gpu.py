@@ -6,6 +6,7 @@ import os
 import re
 import shutil
 import subprocess
+import time
 
 import pytest
 
@@ -15,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 REFBIN = os.path.join(ROOT, "oracle", "_ref", "bin")
 PLUGINS = os.path.join(ROOT, "smart_amd", "bin", "plugins")
-ALGOS = ["hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8"]
+ALGOS = ["hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8", "sbndm"]
 
 
 @pytest.fixture(scope="module")
@@ -50,14 +51,32 @@ def smart_tree(tmp_path_factory, oracle):
 @pytest.mark.parametrize("algo", ALGOS)
 def test_reference_test_binary_passes(smart_tree, algo):
     d, env = smart_tree
-    r = subprocess.run(["./test", algo], cwd=str(d), env=env, capture_output=True, text=True, timeout=600)
+    # The reference draws its five SysV keys from rand() % 1000 seeded with time(NULL) and the loop that
+    # draws the COUNT segment's key (src/test.c:205-209) compares pkey, not rkey, with ekey/prekey: about
+    # 2 runs in 1000 the count and a timing segment are the same memory and the reference reads a garbage
+    # count (seen once: "found 0 occ instead of 10" on case 1).  A failed run is repeated after the seed
+    # has changed; a real defect fails every time.
+    for attempt in range(3):
+        r = subprocess.run(["./test", algo], cwd=str(d), env=env, capture_output=True, text=True, timeout=600)
+        if "Well done! Test passed successfully" in r.stdout:
+            break
+        time.sleep(1.1)
     assert "Well done! Test passed successfully" in r.stdout, r.stdout + r.stderr
 
 
 def test_reference_smart_binary_reports_ok(smart_tree):
     d, env = smart_tree
-    r = subprocess.run(["./smart", "-text", "rand128", "-plen", "32", "32", "-pset", "3", "-occ", "-pre"],
-                       cwd=str(d), env=env, capture_output=True, text=True, timeout=900)
+
+    def ok(out):
+        lines = [ln for ln in out.splitlines() if re.search(r"\] [A-Z0-9]+ \.", ln)]
+        return len(lines) == len(ALGOS) and all("[OK]" in ln for ln in lines)
+
+    for attempt in range(3):  # same key-collision hazard as above (src/smart.c:262-267)
+        r = subprocess.run(["./smart", "-text", "rand128", "-plen", "32", "32", "-pset", "3", "-occ", "-pre"],
+                           cwd=str(d), env=env, capture_output=True, text=True, timeout=900)
+        if ok(r.stdout):
+            break
+        time.sleep(1.1)
     out = r.stdout
     assert "Testing %d algorithms" % len(ALGOS) in out, out + r.stderr
     for a in ALGOS:
