@@ -588,6 +588,31 @@ uint64_t oracle_sbndm(const uint8_t *P, int m, const uint8_t *T, uint64_t n)
     return hits;
 }
 
+/* Karp-Rabin: a rolling hash of the window, h = sum T[s+i] * 2^(m-1-i) in
+ * 32-bit arithmetic (so only the last 32 bytes of a longer window still
+ * count), compared with the pattern's; equal hashes are confirmed byte by
+ * byte.  reference: src/algos/kr.c:26-54 (REHASH :26; it reads T[n] when it
+ * rolls past the last window, this restatement does not). */
+uint64_t oracle_kr(const uint8_t *P, int m, const uint8_t *T, uint64_t n)
+{
+    if (m <= 0 || (uint64_t)m > n) return 0;
+    uint32_t top = 1;  /* 2^(m-1) mod 2^32: the weight of the byte that leaves */
+    for (int i = 1; i < m; ++i) top <<= 1;
+    uint32_t hp = 0, ht = 0;
+    for (int i = 0; i < m; ++i) {
+        hp = (hp << 1) + P[i];
+        ht = (ht << 1) + T[i];
+    }
+    uint64_t hits = 0;
+    const uint64_t last = n - (uint64_t)m;
+    for (uint64_t s = 0;; ++s) {
+        if (hp == ht && memcmp(P, T + s, (size_t)m) == 0) ++hits;
+        if (s == last) break;
+        ht = ((ht - (uint32_t)T[s] * top) << 1) + T[s + (uint64_t)m];
+    }
+    return hits;
+}
+
 /* ------------------------------------------------------------------ */
 /* dispatch                                                            */
 /* ------------------------------------------------------------------ */
@@ -601,7 +626,7 @@ static oracle_fn lookup(const char *name)
         {"epsm", oracle_epsm}, {"sa", oracle_sa},     {"qs", oracle_qs},
         {"tunedbm", oracle_tunedbm}, {"raita", oracle_raita},
         {"hash3", oracle_hash3}, {"hash5", oracle_hash5}, {"hash8", oracle_hash8},
-        {"sbndm", oracle_sbndm},
+        {"sbndm", oracle_sbndm}, {"kr", oracle_kr},
     };
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i)
         if (strcmp(tab[i].name, name) == 0) return tab[i].fn;

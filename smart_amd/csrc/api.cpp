@@ -122,7 +122,7 @@ struct smartgpu_plan {
 namespace {
 
 const char* kAlgoNames[SMARTGPU_NUM_ALGOS] = {"hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita",
-                                              "hash3", "hash5", "hash8", "sbndm"};
+                                              "hash3", "hash5", "hash8", "sbndm", "kr"};
 
 // shortest pattern an algorithm applies to (the reference returns -1 below it: raita.c:37, hash3.c:31, ...)
 uint32_t min_pattern(int algo)
@@ -285,6 +285,13 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         case SMARTGPU_EPSM:
             append_fingerprint();
             break;
+        case SMARTGPU_KR: {  // kr.c:38-41: the pattern's hash; weights 2^(m-1-i) mod 2^32 vanish beyond 32 bytes
+            uint32_t hp = 0;
+            for (uint32_t i = 0; i < m; ++i) hp = (hp << 1) + P[i];
+            append(&hp, 4);
+            *halo = std::min<uint32_t>(m - 1, 32);  // bytes confirmed in LDS (and the hash's reach) behind a window end
+            break;
+        }
         case SMARTGPU_SA: {
             const std::vector<uint32_t> S = sg::shift_and_masks(P, m);
             append(S.data(), 1024);
@@ -740,6 +747,7 @@ int smartgpu_hash3_search(const unsigned char* P, int m, const unsigned char* T,
 int smartgpu_hash5_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_HASH5, P, m, T, n); }
 int smartgpu_hash8_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_HASH8, P, m, T, n); }
 int smartgpu_sbndm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_SBNDM, P, m, T, n); }
+int smartgpu_kr_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_KR, P, m, T, n); }
 
 /* ---- one process, several GPUs ------------------------------------------ */
 }  // extern "C"

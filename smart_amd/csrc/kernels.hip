@@ -294,6 +294,13 @@ __device__ __forceinline__ uint32_t bp_addr(uint32_t P)
     return ((P & 63u) >> 2) * kBpRowBytes + (P >> 6) * 4u + (P & 3u);
 }
 
+// KR = true: Karp-Rabin (kr.c:26-54) on the same transposed tiles.  Every lane rolls a hash over
+// its own 64 window ends, one byte in and (m < 32) one byte out per step, all lanes in lockstep:
+// exactly the access pattern that would be a 32-way bank conflict on a flat tile and is conflict-
+// free here, where lane q's bytes live in bank q.  The hash is the reference's: 32-bit, weights
+// 2^(m-1-i), so of a window longer than 32 bytes only the last 32 still count and nothing has to
+// be subtracted; an equal hash is confirmed byte by byte (LDS through the halo, then memory).
+template <bool KR>
 __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t tile_first,
                                                           uint32_t ntiles)
 {
@@ -305,11 +312,13 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
     uint8_t* txt = ptail + round16(H + 1);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
 
-    {   // 64 rows (4 chars each) x 32 banks: every bank gets the same packed dword
+    if (!KR) {  // 64 rows (4 chars each) x 32 banks: every bank gets the same packed dword
         const uint32_t* g = reinterpret_cast<const uint32_t*>(a.blob + kTableOff + 512);
         uint32_t* t32 = reinterpret_cast<uint32_t*>(ptab);
         for (uint32_t i = tid; i < 2048; i += kBpThreads) t32[i] = g[i >> 5];
     }
+    const uint32_t kr_w = m < 32 ? m : 32;                                              // bytes the hash still sees
+    const uint32_t kr_hp = KR ? *reinterpret_cast<const uint32_t*>(a.blob + kTableOff) : 0u;  // the pattern's hash
     for (uint32_t i = tid; i <= H; i += kBpThreads) ptail[i] = a.blob[m - 1 - H + i];
     const uint32_t plast = a.blob[m - 1];
     const uint32_t my_tab = (lane & 31u) * 4u;
@@ -367,7 +376,55 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
         if (lo < hi) {
             uint32_t e = (uint32_t)(lo - tile0) + kBpHB;  // P-coordinates
             const uint32_t ehi = (uint32_t)(hi - tile0) + kBpHB;
-            {
+            if (KR && kr_w == 32 && lo == seg && hi == seg + kBpL) {
+                // m >= 32 and a whole lane: the 64 window ends are this lane's own column, 16 dwords at
+                // compile-time offsets; nothing leaves the 32-bit hash, so a step is shift + add.
+                // Equal hashes are rare: a running minimum of h ^ hp says whether a group of 16 has
+                // one, and only then are its ends looked at one by one.
+                uint32_t h = 0;
+                for (uint32_t k = 1; k <= 32; ++k) h += (uint32_t)txt[bp_addr(e - k)] << (k - 1);  // window ending at e-1
+                const uint8_t* col = txt + (kBpHaloCols + tid) * 4u;
+#pragma unroll 1
+                for (uint32_t g = 0; g < 4; ++g) {
+                    const uint32_t h0 = h;
+                    uint32_t d[4], near = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d[r] = *reinterpret_cast<const uint32_t*>(col + (4 * g + r) * kBpRowBytes);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        h = (h << 1) + ((d[i >> 2] >> (8 * (i & 3))) & 0xFFu);  // kr.c:26,48
+                        near = min(near, h ^ kr_hp);
+                    }
+                    if (near == 0) {  // kr.c:47: some end in this group has the pattern's hash: confirm
+                        uint32_t hh = h0;
+                        for (uint32_t i = 0; i < 16; ++i) {
+                            const uint32_t ee = e + 16 * g + i;
+                            hh = (hh << 1) + txt[bp_addr(ee)];
+                            if (hh != kr_hp) continue;
+                            uint32_t k = 0;
+                            while (k <= H && ptail[H - k] == txt[bp_addr(ee - k)]) ++k;
+                            bool ok = k == H + 1;
+                            if (ok && m - 1 > H) ok = global_equal(a.text + tile0 + (ee - kBpHB) - (m - 1), a.blob, m - 1 - H);
+                            hits += ok;
+                        }
+                    }
+                }
+            } else if (KR) {
+                uint32_t h = 0;  // hash of the window ending at e (kr.c:38-41)
+                for (uint32_t k = 0; k < kr_w; ++k) h += (uint32_t)txt[bp_addr(e - k)] << k;
+                for (;;) {
+                    if (h == kr_hp) {  // kr.c:47: confirm
+                        uint32_t k = 0;
+                        while (k <= H && ptail[H - k] == txt[bp_addr(e - k)]) ++k;
+                        bool ok = k == H + 1;
+                        if (ok && m - 1 > H) ok = global_equal(a.text + tile0 + (e - kBpHB) - (m - 1), a.blob, m - 1 - H);
+                        hits += ok;
+                    }
+                    if (++e >= ehi) break;
+                    h = (h << 1) + txt[bp_addr(e)];                                  // kr.c:26,48: one byte in ...
+                    if (kr_w < 32) h -= (uint32_t)txt[bp_addr(e - kr_w)] << kr_w;  // ... one byte out (weight 2^m)
+                }
+            } else {
                 while (e < ehi) {
                     const uint32_t c = txt[bp_addr(e)];
                     const uint32_t shift = ptab[(c >> 2) * 128u + my_tab + (c & 3u)];
@@ -1870,6 +1927,7 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
         case SMARTGPU_RAITA:
         case SMARTGPU_QS: return (pk || hor_regime(m, algo) == 3) ? "packed_scan" : "hor_scan";
         case SMARTGPU_SA: return "so_runs";
+        case SMARTGPU_KR: return "hor_scan_bp";
         case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : "kmp_runs";
         case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : "so_runs";
@@ -2033,12 +2091,18 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             if (regime == 2) {
                 const size_t lds = kBpTabBytes + r16(H + 1) + kBpTextBytes;
                 const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBpThreads * kBpL);
-                return launch_tiled(hor_scan_bp, a, tr, kBpThreads, lds, 5, num_cus, stream);
+                return launch_tiled(hor_scan_bp<false>, a, tr, kBpThreads, lds, 5, num_cus, stream);
             }
             const size_t lds = 512 + r16(H + 1) + r16(H) + (size_t)kHorT * kHorL;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
             if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 0>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);
             return launch_tiled(hor_scan<kHorT, kHorL, false, 0>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);
+        }
+        case SMARTGPU_KR: {  // rolling hash on the bank-private tiles; a.halo = min(m-1, 32) (api.cpp)
+            const uint32_t H = a.halo;
+            const size_t lds = kBpTabBytes + r16(H + 1) + kBpTextBytes;
+            const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBpThreads * kBpL);
+            return launch_tiled(hor_scan_bp<true>, a, tr, kBpThreads, lds, 5, num_cus, stream);
         }
         case SMARTGPU_HASH3:
         case SMARTGPU_HASH5:
