@@ -373,6 +373,19 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
         const uint64_t seg = tile0 + (uint64_t)tid * kBpL;
         const uint64_t lo = seg > e_begin ? seg : e_begin;
         const uint64_t hi = seg + kBpL < e_end ? seg + kBpL : e_end;
+        bool parked = false;  // KR, m-1 > H: first window of this tile whose hash and last H+1 bytes matched
+        const uint8_t* parked_at = a.text;
+        // the rest of such a window is in memory: the lane parks it for wave_verify below (64 lanes
+        // compare 1 KiB per step) — done by the lane itself, one m=4096 occurrence cost 0.25 ms
+        auto confirm_rest = [&](uint32_t ee) -> bool {
+            const uint8_t* rest = a.text + tile0 + (ee - kBpHB) - (m - 1);
+            if (!parked) {
+                parked = true;
+                parked_at = rest;
+                return false;  // counted by wave_verify
+            }
+            return global_equal(rest, a.blob, m - 1 - H);
+        };
         if (lo < hi) {
             uint32_t e = (uint32_t)(lo - tile0) + kBpHB;  // P-coordinates
             const uint32_t ehi = (uint32_t)(hi - tile0) + kBpHB;
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
                             uint32_t k = 0;
                             while (k <= H && ptail[H - k] == txt[bp_addr(ee - k)]) ++k;
                             bool ok = k == H + 1;
-                            if (ok && m - 1 > H) ok = global_equal(a.text + tile0 + (ee - kBpHB) - (m - 1), a.blob, m - 1 - H);
+                            if (ok && m - 1 > H) ok = confirm_rest(ee);
                             hits += ok;
                         }
                     }
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
                         uint32_t k = 0;
                         while (k <= H && ptail[H - k] == txt[bp_addr(e - k)]) ++k;
                         bool ok = k == H + 1;
-                        if (ok && m - 1 > H) ok = global_equal(a.text + tile0 + (e - kBpHB) - (m - 1), a.blob, m - 1 - H);
+                        if (ok && m - 1 > H) ok = confirm_rest(e);
                         hits += ok;
                     }
                     if (++e >= ehi) break;
@@ -437,6 +450,7 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
                 }
             }
         }
+        if (KR && m - 1 > H) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
     flush_hits(hits, a.count);
 }
