@@ -78,13 +78,25 @@ __device__ __forceinline__ void stage_tile(uint8_t* __restrict__ lds,
         *reinterpret_cast<uint4*>(lds + (k * THREADS + threadIdx.x) * 16) = v[k];
 }
 
-// Sum the per-lane hit counters over the 64-lane wave; one atomic per wave.
-__device__ __forceinline__ void flush_hits(uint32_t lane_hits, unsigned long long* out)
+// Sum the per-lane hit counters over the workgroup; ONE atomic per workgroup.  (One per wave was
+// the first version: on dense hits — short patterns, small alphabets — thousands of atomics on the
+// same result slot serialise behind each other at the end of the kernel.)  `lds` is any 8-byte
+// aligned 128 bytes of the kernel's LDS: every wave is past its last use of the LDS when it gets
+// here, which the first barrier establishes for the whole workgroup.
+__device__ __forceinline__ void flush_hits(uint32_t lane_hits, unsigned long long* out, void* lds)
 {
     unsigned long long v = lane_hits;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(out, v);
+    unsigned long long* part = static_cast<unsigned long long*>(lds);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long sum = 0;
+        for (uint32_t w = 0; w < blockDim.x / 64; ++w) sum += part[w];
+        if (sum != 0) atomicAdd(out, sum);
+    }
 }
 
 // 16 bytes at a (text, any alignment) vs 16 bytes at b (pattern slot), first `nb`
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
         }
         if (LONG) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
-    flush_hits(hits, a.count);
+    flush_hits(hits, a.count, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
         }
         if (KR && m - 1 > H) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
-    flush_hits(hits, a.count);
+    flush_hits(hits, a.count, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -565,7 +577,7 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
         }
         if (LONG) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
-    flush_hits(hits, a.count);
+    flush_hits(hits, a.count, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
         }
         if (LONG) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
     }
-    flush_hits(hits, a.count);
+    flush_hits(hits, a.count, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -816,7 +828,7 @@ __global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a, uint64_t tile_fir
         }
         if (LONG) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
     }
-    flush_hits(hits, a.count);
+    flush_hits(hits, a.count, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -931,7 +943,7 @@ __global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a, uint64_t tile_fi
         if (j < jend)
             kmp_chunk<true>(*reinterpret_cast<const uint4*>(txt + j), j, j0, jend, st, hits, m, p0, next_m, tab);
     }
-    flush_hits(hits, a.count);
+    flush_hits(hits, a.count, smem);
 }
 
 // KMP over per-lane RUNS streamed through LDS.  A lane owns a run of `run_len` start
@@ -1207,7 +1219,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t 
             half(k * kRunLine + 64u);
         }
     }
-    flush_hits(hits, a.count);
+    flush_hits(hits, a.count, smem);
 }
 
 // The failure links followed per byte (the reference's loop, kmp.c:55-66), A/B only: smartgpu_tune(3,2).
@@ -1291,7 +1303,7 @@ __global__ __launch_bounds__(256) void kmp_links_runs(ScanArgs a, uint32_t run_l
             }
         }
     }
-    flush_hits(hits, a.count);
+    flush_hits(hits, a.count, smem);
 }
 
 // Shift-Or over per-lane RUNS (the structure of kmp_runs above).  With LDS tiles a lane's run is
@@ -1445,7 +1457,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
             half(k * kRunLine + 64u);
         }
     }
-    flush_hits(hits, a.count);
+    flush_hits(hits, a.count, smem);
 }
 
 // The first runs kernel: shared 1 KB table, 64-byte steps, [run][80 B] slabs (A/B only).
@@ -1552,7 +1564,7 @@ __global__ __launch_bounds__(256) void so_runs64(ScanArgs a, uint32_t run_len, u
             }
         }
     }
-    flush_hits(hits, a.count);
+    flush_hits(hits, a.count, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -1659,6 +1671,7 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_
     // (Both loads nt measured 62-67 %: the second load must find the line still cached.  A
     // ballot/SGPR formulation of the first-dword test measured 59-73 %: scalar-unit bound.)
     constexpr bool NTA = POLICY != 1, NTB = false;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 128 bytes: flush_hits
     const uint32_t* fpw = reinterpret_cast<const uint32_t*>(a.blob + a.fp_off);
     EpsmFp fp;
     fp.f0 = fpw[0]; fp.f1 = fpw[1]; fp.f2 = fpw[2]; fp.f3 = fpw[3];
@@ -1723,7 +1736,7 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_
             }
         }
     }
-    flush_hits(hits, a.count);
+    flush_hits(hits, a.count, smem);
 }
 
 // Occurrence POSITIONS (an extension: the reference only counts, define.h:33).  The packed
@@ -2033,7 +2046,7 @@ static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stre
     const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 8);
     if (grid > cap) grid = cap;
 #define SG_PACKED(M_, P_)                                                                           \
-    hipLaunchKernelGGL((packed_scan<kEpsmT, 4, ALGO, M_, P_>), dim3((uint32_t)grid), dim3(kEpsmT), 0,   \
+    hipLaunchKernelGGL((packed_scan<kEpsmT, 4, ALGO, M_, P_>), dim3((uint32_t)grid), dim3(kEpsmT), 128, \
                        stream, a, tr.first, (uint64_t)tr.count)
 #define SG_PACKED_POLICY(M_)                                                 \
     do {                                                                     \
