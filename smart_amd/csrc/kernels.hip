@@ -2041,9 +2041,10 @@ static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stre
     if (tr.count == 0) return hipSuccess;
     const int rows = 4;  // rows in flight per workgroup step (1 and 2 measured slower, profiles/r01)
     uint64_t grid = ((uint64_t)tr.count + rows - 1) / rows;
-    // (32 workgroups per CU measured 77-82 % against 75-77 % on sparse hits, but every wave with hits
-    // ends in an atomic on the result slot and same-address atomics serialise: 34 % on dense hits)
-    const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 8);
+    // no LDS tile, no barrier in the loop: more, smaller shares balance better — 16 workgroups per
+    // CU (two rounds) measured 76-79 % against 73-77 % with 8 on sparse hits and the same on dense
+    // ones; beyond that the atomics on the result slot (one per workgroup with hits) show
+    const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 16);
     if (grid > cap) grid = cap;
 #define SG_PACKED(M_, P_)                                                                           \
     hipLaunchKernelGGL((packed_scan<kEpsmT, 4, ALGO, M_, P_>), dim3((uint32_t)grid), dim3(kEpsmT), 128, \
