@@ -1182,23 +1182,34 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t 
             if (jb >= j0 && jb + 64u <= jend) {  // the whole half is inside the run
                 bool seen = false;
                 if (!dense) {
-                    const uint32_t st0 = st;
-                    uint32_t mx = 0;
+                    uint32_t at[5], mx[4];  // state before each 16-byte chunk, running maximum inside it
+                    at[0] = st;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) kmp_dfa_chunk_max(run_piece(io, q), st, mx);
-                    seen = mx == w;
-                    if (seen) {  // the accept state was reached: walk the step again, counting
-                        st = st0;
-#pragma unroll 1
-                        for (int q = 0; q < 4; ++q) careful(q, true);
+                    for (int q = 0; q < 4; ++q) {
+                        mx[q] = 0;
+                        kmp_dfa_chunk_max(run_piece(io, q), st, mx[q]);
+                        at[q + 1] = st;
                     }
+                    // chunks that reached the accept state are walked again, counting (one copy of
+                    // that code: the chunk index is a run-time value)
+                    uint32_t todo = (mx[0] == w ? 1u : 0u) | (mx[1] == w ? 2u : 0u) | (mx[2] == w ? 4u : 0u) | (mx[3] == w ? 8u : 0u);
+                    seen = todo != 0;
+#pragma unroll 1
+                    while (todo) {
+                        const int q = __builtin_ctz(todo);
+                        todo &= todo - 1;
+                        st = q == 0 ? at[0] : q == 1 ? at[1] : q == 2 ? at[2] : at[3];
+                        careful(q, true);
+                    }
+                    st = at[4];
                 } else {
 #pragma unroll 1
                     for (int q = 0; q < 4; ++q) seen |= careful(q, true);
                 }
                 // where occurrences are frequent (short patterns, small alphabets) walking twice
-                // costs more than it saves: the wave counts directly while its last step saw any
-                dense = __any(seen);
+                // costs more than it saves: the wave counts directly while an eighth of its lanes
+                // saw one in the last half
+                dense = __popcll(__ballot(seen)) >= 8;
             } else {
 #pragma unroll 1
                 for (int q = 0; q < 4; ++q) {
