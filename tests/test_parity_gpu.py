@@ -243,6 +243,35 @@ def test_large_patterns_and_periodic_text(oracle):
             assert got[a] == want, (a, m, got)
 
 
+def test_occurrences_across_tile_and_lane_boundaries(oracle):
+    """Occurrences planted so that they start, end and straddle the kernels' work boundaries:
+    16 KiB tiles, 64-byte lane segments, 2 KiB runs, 4 KiB packed rows (the forward byte of
+    Quick Search, the back halo of the hash and rolling-hash variants, the run restarts)."""
+    rng = np.random.default_rng(2024)
+    n = 5 * 16384 + 777
+    for m in (2, 3, 8, 17, 33, 64, 100, 300):
+        T = rng.integers(0, 250, n, dtype=np.uint8)
+        P = rng.integers(0, 250, m, dtype=np.uint8)
+        P[-1] = 251  # bytes outside the text's alphabet: only planted copies match
+        P[0] = 252
+        spots = []
+        for edge in (2048, 4096, 16384, 32768, 49152, 65536):
+            for d in (-m - 1, -m, -m + 1, -1, 0, 1, 63 - m, 64 - m):
+                k = edge + d
+                if 0 <= k and k + m <= n and all(abs(k - q) >= m for q in spots):
+                    spots.append(k)
+        spots += [0, n - m]
+        for k in spots:
+            T[k:k + m] = P
+        want = oracle.search("bf", P, T)
+        assert want == len(set(spots))
+        text = Text.upload(T)
+        got = gpu_counts(P, text)
+        text.free()
+        for a in got:
+            assert got[a] == want, (a, m, got[a], want)
+
+
 def test_small_alphabets_dense_matches(oracle):
     """BASELINE config 3 regime: sigma 2 and 4, m <= 64, many occurrences."""
     for sigma in (2, 4):
