@@ -62,7 +62,8 @@ enum {
     SMARTGPU_HASH8 = 12,  /* src/algos/hash8.c   ... of the last 8 bytes; m >= 8 */
     SMARTGPU_SBNDM = 13,  /* src/algos/sbndm.c   Simplified BNDM; m >= 2 */
     SMARTGPU_KR = 14,     /* src/algos/kr.c      Karp-Rabin: rolling 32-bit hash + confirmation */
-    SMARTGPU_NUM_ALGOS = 15
+    SMARTGPU_BNDML = 15,  /* src/algos/bndml.c   BNDM with multi-word bit vectors for m > 32 */
+    SMARTGPU_NUM_ALGOS = 16
 };
 
 typedef struct smartgpu_text smartgpu_text; /* a text resident in one GPU's HBM */
@@ -72,7 +73,7 @@ typedef struct smartgpu_plan smartgpu_plan; /* one (algorithm, pattern) with its
 const char *smartgpu_version(void);
 const char *smartgpu_last_error(void);
 int smartgpu_device_count(void);                   /* <0 on error */
-int smartgpu_algo_id(const char *name);            /* "hor","bm","kmp","so","bndm","epsm","sa","qs","tunedbm","raita","hash3","hash5","hash8","sbndm","kr" (any case); -1 unknown */
+int smartgpu_algo_id(const char *name);            /* "hor","bm","kmp","so","bndm","epsm","sa","qs","tunedbm","raita","hash3","hash5","hash8","sbndm","kr","bndml" (any case); -1 unknown */
 const char *smartgpu_algo_name(int algo);          /* NULL if out of range */
 int smartgpu_device_sync(int device);              /* waits for the library's stream on `device` */
 
@@ -122,6 +123,7 @@ int smartgpu_hash5_search(const unsigned char *P, int m, const unsigned char *T,
 int smartgpu_hash8_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* hash8.c; -1 for m < 8 */
 int smartgpu_sbndm_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* sbndm.c:28-149; -1 for m < 2 */
 int smartgpu_kr_search(const unsigned char *P, int m, const unsigned char *T, int n);      /* kr.c:28-54 */
+int smartgpu_bndml_search(const unsigned char *P, int m, const unsigned char *T, int n);   /* bndml.c:44-132 */
 /* pre/run times (ms) of the last search on this thread (main.h:34-35 globals) */
 void smartgpu_last_times(double *pre_ms, double *run_ms);
 

@@ -613,6 +613,46 @@ uint64_t oracle_kr(const uint8_t *P, int m, const uint8_t *T, uint64_t n)
     return hits;
 }
 
+/* BNDM with multi-word bit vectors for patterns longer than a word: no
+ * prefix trick, the whole pattern lives in ceil(m/32) words and the shift
+ * carries from word to word.  reference: src/algos/bndml.c:44-75 (m <= 32:
+ * plain BNDM), search_large bndml.c:82-132.  Bit i of B[c] <=> P[m-1-i] == c;
+ * bit m-1 of D after k bytes <=> the last k window bytes are a prefix of P. */
+uint64_t oracle_bndml(const uint8_t *P, int m, const uint8_t *T, uint64_t n)
+{
+    if (m <= 0 || (uint64_t)m > n) return 0;
+    if (m <= 32) return oracle_bndm(P, m, T, n);
+    const int W = (m + 31) / 32;
+    uint32_t *B = calloc((size_t)ORACLE_SIGMA * (size_t)W, sizeof *B);
+    uint32_t *D = calloc((size_t)W, sizeof *D);
+    if (!B || !D) { free(B); free(D); return UINT64_MAX; }
+    for (int i = 0; i < m; ++i) B[(size_t)P[m - 1 - i] * W + i / 32] |= 1u << (i % 32);
+    uint64_t hits = 0, e = (uint64_t)m - 1;  /* window end */
+    while (e < n) {
+        const uint32_t *b = B + (size_t)T[e] * W;
+        int alive = 0, k = 1, longest = 0;
+        for (int i = 0; i < W; ++i) { D[i] = b[i]; alive |= D[i] != 0; }
+        while (k < m && alive) {
+            if (D[(m - 1) / 32] & (1u << ((m - 1) % 32))) longest = k;
+            b = B + (size_t)T[e - (uint64_t)k] * W;
+            uint32_t carry = 0;
+            alive = 0;
+            for (int i = 0; i < W; ++i) {
+                const uint32_t cur = D[i];
+                D[i] = ((cur << 1) | carry) & b[i];
+                carry = cur >> 31;
+                alive |= D[i] != 0;
+            }
+            ++k;
+        }
+        hits += alive != 0;
+        e += (uint64_t)(m - longest);
+    }
+    free(B);
+    free(D);
+    return hits;
+}
+
 /* ------------------------------------------------------------------ */
 /* dispatch                                                            */
 /* ------------------------------------------------------------------ */
@@ -626,7 +666,7 @@ static oracle_fn lookup(const char *name)
         {"epsm", oracle_epsm}, {"sa", oracle_sa},     {"qs", oracle_qs},
         {"tunedbm", oracle_tunedbm}, {"raita", oracle_raita},
         {"hash3", oracle_hash3}, {"hash5", oracle_hash5}, {"hash8", oracle_hash8},
-        {"sbndm", oracle_sbndm}, {"kr", oracle_kr},
+        {"sbndm", oracle_sbndm}, {"kr", oracle_kr},       {"bndml", oracle_bndml},
     };
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i)
         if (strcmp(tab[i].name, name) == 0) return tab[i].fn;

@@ -52,8 +52,10 @@ uint64_t oracle_hash8(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
 uint64_t oracle_sbndm(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
 /* kr.c (Karp-Rabin) */
 uint64_t oracle_kr(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
+/* bndml.c (BNDM with multi-word bit vectors) */
+uint64_t oracle_bndml(const uint8_t *P, int m, const uint8_t *T, uint64_t n);
 
-/* name in {"bf","hor","bm","kmp","so","bndm","epsm","sa","qs","tunedbm","raita","hash3","hash5","hash8","sbndm","kr"}; returns -1 for an
+/* name in {"bf","hor","bm","kmp","so","bndm","epsm","sa","qs","tunedbm","raita","hash3","hash5","hash8","sbndm","kr","bndml"}; returns -1 for an
  * unknown name or a count that does not fit an int (SMART's -1 convention,
  * src/algos/include/main.h:39 and e.g. ssef.c:41). */
 int oracle_search_int(const char *name, const uint8_t *P, int m,

@@ -122,7 +122,7 @@ struct smartgpu_plan {
 namespace {
 
 const char* kAlgoNames[SMARTGPU_NUM_ALGOS] = {"hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita",
-                                              "hash3", "hash5", "hash8", "sbndm", "kr"};
+                                              "hash3", "hash5", "hash8", "sbndm", "kr", "bndml"};
 
 // shortest pattern an algorithm applies to (the reference returns -1 below it: raita.c:37, hash3.c:31, ...)
 uint32_t min_pattern(int algo)
@@ -268,6 +268,16 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             append(S.data(), 1024);
             break;
         }
+        case SMARTGPU_BNDML:
+            if (m > 32) {  // bndml.c:91-93: bit i of word i/32 of B[c] <=> P[w-1-i] == c, over w = min(m, 256) bytes
+                const uint32_t w = std::min<uint32_t>(m, 256);
+                const uint32_t W = w <= 64 ? 2 : w <= 128 ? 4 : 8;
+                std::vector<uint32_t> B(256 * W, 0u);
+                for (uint32_t i = 0; i < w; ++i) B[P[w - 1 - i] * W + i / 32] |= 1u << (i % 32);
+                append(B.data(), B.size() * 4);
+                break;
+            }
+            [[fallthrough]];  // m <= 32: plain BNDM (bndml.c:44-75)
         case SMARTGPU_SBNDM:
         case SMARTGPU_BNDM: {
             const std::vector<uint32_t> B = sg::bndm_masks(P, m);
@@ -748,6 +758,7 @@ int smartgpu_hash5_search(const unsigned char* P, int m, const unsigned char* T,
 int smartgpu_hash8_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_HASH8, P, m, T, n); }
 int smartgpu_sbndm_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_SBNDM, P, m, T, n); }
 int smartgpu_kr_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_KR, P, m, T, n); }
+int smartgpu_bndml_search(const unsigned char* P, int m, const unsigned char* T, int n) { return search_host(SMARTGPU_BNDML, P, m, T, n); }
 
 /* ---- one process, several GPUs ------------------------------------------ */
 }  // extern "C"

@@ -712,6 +712,116 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
 }
 
 // ---------------------------------------------------------------------------
+// BNDM with multi-word bit vectors  (src/algos/bndml.c:82-132, search_large; m <= 32 is plain BNDM
+// and runs on bndm_scan).  The whole window lives in W = 2, 4 or 8 words held in registers, the
+// shift carries from word to word, bit w-1 of D after k bytes says "the last k bytes are a prefix
+// of P" (shift = w - longest such k).  w = min(m, 256): the reference keeps ceil(m/32) words for
+// any m (its table is 128 KB at m = 4096); here a pattern longer than 256 bytes is filtered by its
+// 256-byte prefix and the rest is verified in memory, as the single-word algorithms do with 32.
+// Tiles are indexed by the END of the w-byte window with a 256-byte back halo.
+// LDS: u32 B[256][W] | text [tile0-256, tile0+TB)
+// ---------------------------------------------------------------------------
+template <int THREADS, int L, int W, bool LONG>  // LONG: m > 256
+__global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a, uint64_t tile_first, uint32_t ntiles)
+{
+    constexpr int TB = THREADS * L;
+    constexpr uint32_t H16 = 256;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m, w = m < 256 ? m : 256;
+    uint32_t* B = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* txt = smem + 256 * W * 4;
+    for (uint32_t i = threadIdx.x; i < 256 * W; i += THREADS)
+        B[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i];
+    const uint32_t top_word = (w - 1) >> 5, top_bit = 1u << ((w - 1) & 31u);
+
+    const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
+    uint32_t hits = 0;
+    static_assert(TB == THREADS * 64, "prefetch registers are written out for L = 64");
+    uint4 p0, p1, p2, p3, ph;  // prefetch registers: 4 tile rows + one halo chunk
+    const bool halo_lane = threadIdx.x * 16u < H16;
+    auto issue = [&](uint64_t tile0) {
+        const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
+        p0 = ld_stream16(src);
+        p1 = ld_stream16(src + THREADS * 16);
+        p2 = ld_stream16(src + THREADS * 32);
+        p3 = ld_stream16(src + THREADS * 48);
+        if (halo_lane) ph = *reinterpret_cast<const uint4*>(src - H16);
+    };
+    const uint64_t t_end = tile_first + ntiles;
+    uint64_t t = tile_first + blockIdx.x;
+    issue(t * TB);
+    for (; t < t_end; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();
+        {
+            uint8_t* dst = txt + H16 + threadIdx.x * 16u;
+            *reinterpret_cast<uint4*>(dst) = p0;
+            *reinterpret_cast<uint4*>(dst + THREADS * 16) = p1;
+            *reinterpret_cast<uint4*>(dst + THREADS * 32) = p2;
+            *reinterpret_cast<uint4*>(dst + THREADS * 48) = p3;
+            if (halo_lane) *reinterpret_cast<uint4*>(txt + threadIdx.x * 16u) = ph;
+        }
+        __syncthreads();
+        if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
+        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+        const uint64_t lo = seg > e_begin ? seg : e_begin;
+        const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+        bool parked = false;  // first candidate of this tile awaiting wave_verify
+        const uint8_t* parked_at = a.text;
+        if (lo < hi) {
+            uint32_t e = (uint32_t)(lo - tile0) + H16;
+            const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
+            while (e < ehi) {
+                uint32_t D[W], alive = 0;
+                {
+                    const uint32_t* b = B + (uint32_t)txt[e] * W;  // bndml.c:100-103
+#pragma unroll
+                    for (int i = 0; i < W; ++i) { D[i] = b[i]; alive |= D[i]; }
+                }
+                if (alive == 0) {  // the byte does not occur in the (prefix of the) pattern
+                    e += w;
+                    continue;
+                }
+                uint32_t k = 1, longest = 0;
+                while (k < w && alive != 0) {  // bndml.c:104-116
+                    uint32_t top = 0;
+#pragma unroll
+                    for (int i = 0; i < W; ++i) top = (uint32_t)i == top_word ? D[i] : top;
+                    if (top & top_bit) longest = k;
+                    const uint32_t* b = B + (uint32_t)txt[e - k] * W;
+                    uint32_t carry = 0;
+                    alive = 0;
+#pragma unroll
+                    for (int i = 0; i < W; ++i) {
+                        const uint32_t cur = D[i];
+                        D[i] = ((cur << 1) | carry) & b[i];
+                        carry = cur >> 31;
+                        alive |= D[i];
+                    }
+                    ++k;
+                }
+                if (alive != 0) {  // all w bytes matched
+                    if (!LONG) {
+                        ++hits;
+                    } else {
+                        const uint8_t* rest = a.text + tile0 + (e - H16) + 1;  // = text + s + w
+                        if (!parked) {
+                            parked = true;
+                            parked_at = rest;
+                        } else {
+                            hits += global_equal(rest, a.blob + w, m - w);
+                        }
+                    }
+                }
+                e += w - longest;  // bndml.c:118
+            }
+        }
+        if (LONG) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
+    }
+    flush_hits(hits, a.count, smem);
+}
+
+// ---------------------------------------------------------------------------
 // Shift-Or, 32-bit words like the reference  (src/algos/so.c:27-96)
 // Tiles indexed by START position; a lane scans bytes [a, b+w-1) with the state
 // all-ones at a (w = min(m,32)).  L/16 is odd so the lanes' 16-byte LDS reads
@@ -1973,6 +2083,9 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
         case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : "kmp_runs";
         case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : "so_runs";
+        case SMARTGPU_BNDML:
+            if (m > 32) return "bndml_scan";
+            [[fallthrough]];
         case SMARTGPU_SBNDM:
         case SMARTGPU_BNDM: return (pk || (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1)) ? "packed_scan" : "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
@@ -2186,6 +2299,22 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             if (m - 1 > H) return launch_tiled(bm_scan<kBmT, kBmL, true>, a, tr, kBmT, lds, wgs, num_cus, stream);
             return launch_tiled(bm_scan<kBmT, kBmL, false>, a, tr, kBmT, lds, wgs, num_cus, stream);
         }
+        case SMARTGPU_BNDML:
+            if (m > 32) {  // multi-word vectors; m <= 32 is plain BNDM (bndml.c:44-75): falls through
+                const uint32_t w = m < 256 ? m : 256;
+                const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
+#define SG_BNDML(W_)                                                                                      \
+    do {                                                                                                  \
+        const size_t lds = 256 * (W_) * 4 + 256 + (size_t)kBndmT * kBndmL;                                \
+        if (m > 256) return launch_tiled(bndml_scan<kBndmT, kBndmL, W_, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream); \
+        return launch_tiled(bndml_scan<kBndmT, kBndmL, W_, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);            \
+    } while (0)
+                if (w <= 64) SG_BNDML(2);
+                if (w <= 128) SG_BNDML(4);
+                SG_BNDML(8);
+#undef SG_BNDML
+            }
+            [[fallthrough]];
         case SMARTGPU_SBNDM:
         case SMARTGPU_BNDM: {
             if ((m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SMARTGPU_LIB overrides the library path (A/B runs of two builds in one session)
 LIB_PATH = os.environ.get("SMARTGPU_LIB") or os.path.join(_HERE, "csrc", "libsmartgpu.so")
-ALGOS = ("hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8", "sbndm", "kr")
+ALGOS = ("hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8", "sbndm", "kr", "bndml")
 # shortest pattern each algorithm applies to (the reference returns -1 below: raita.c:37, hash3.c:31, ...)
 MIN_M = {"raita": 2, "hash3": 3, "hash5": 5, "hash8": 8, "sbndm": 2}
 

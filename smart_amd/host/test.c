@@ -78,6 +78,7 @@ int main(int argc, char **argv)
         case SMARTGPU_HASH8: algo = smartgpu_hash8_search; min_m = 8; break;
         case SMARTGPU_SBNDM: algo = smartgpu_sbndm_search; min_m = 2; break;
         case SMARTGPU_KR: algo = smartgpu_kr_search; break;
+        case SMARTGPU_BNDML: algo = smartgpu_bndml_search; break;
         default: printf("\tunknown algorithm %s\n", argv[1]); return 1;
     }
     if (smartgpu_device_count() < 1) { fprintf(stderr, "test: no GPU: %s\n", smartgpu_last_error()); return 1; }

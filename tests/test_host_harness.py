@@ -59,7 +59,7 @@ def test_test_tool_usage():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo", ["hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8", "sbndm", "kr"])
+@pytest.mark.parametrize("algo", ["hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8", "sbndm", "kr", "bndml"])
 def test_reference_cases_through_plugin_shape(algo):
     r = run("test", algo)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -73,17 +73,17 @@ def test_smart_report_lines(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
     assert "Searching for a set of 5 patterns with length 32" in out
-    assert "Testing 15 algorithms" in out
-    for name in ("HOR", "BM", "KMP", "SO", "BNDM", "EPSM", "SA", "QS", "TUNEDBM", "RAITA", "HASH3", "HASH5", "HASH8", "SBNDM", "KR"):
+    assert "Testing 16 algorithms" in out
+    for name in ("HOR", "BM", "KMP", "SO", "BNDM", "EPSM", "SA", "QS", "TUNEDBM", "RAITA", "HASH3", "HASH5", "HASH8", "SBNDM", "KR", "BNDML"):
         line = [ln for ln in out.splitlines() if re.search(r"\] %s \." % name, ln)]
         assert line and "[OK]" in line[0] and "occ 1" in line[0] and "GB/s" in line[0], (name, out)
         assert re.search(r"\d+\.\d\d \+ \d+\.\d\d ms", line[0])
     table = list((tmp_path / "results").glob("EXP*/rand128.txt"))
     assert table and table[0].read_text().startswith("HOR")
     xml = list((tmp_path / "results").glob("EXP*/rand128.xml"))[0].read_text()
-    assert xml.startswith("<RESULTS>") and xml.count("<NAME>") == 15 and "<SEARCH>" in xml and "<BEST>" in xml
+    assert xml.startswith("<RESULTS>") and xml.count("<NAME>") == 16 and "<SEARCH>" in xml and "<BEST>" in xml
     tex = list((tmp_path / "results").glob("EXP*/rand128.tex"))[0].read_text()
     assert tex.startswith("\\begin{tabular}{|l|l|}") and "\\textsc{HOR} & " in tex and tex.endswith("\\end{tabular}")
     # -simple: the reference's own example (SURVEY.md §5 hazard 3 segfaults EPSM there)
     r = run("smart", "-simple", "aba", "ababababab", "-pset", "1", "-occ", cwd=str(tmp_path))
-    assert r.stdout.count("occ 4") == 13, r.stdout  # hash5/hash8 do not apply to m = 3
+    assert r.stdout.count("occ 4") == 14, r.stdout  # hash5/hash8 do not apply to m = 3

@@ -8,7 +8,7 @@ import pytest
 
 from conftest import fuzz_case, load_golden
 
-ALGOS = ("bf", "hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8", "sbndm", "kr")
+ALGOS = ("bf", "hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8", "sbndm", "kr", "bndml")
 MIN_M = {"raita": 2, "hash3": 3, "hash5": 5, "hash8": 8, "sbndm": 2}  # below: the reference returns -1 (raita.c:37, hash3.c:31, ...)
 
 # md5 of the 5,000,000-byte corpora src/textgen.c writes

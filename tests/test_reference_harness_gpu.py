@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 REFBIN = os.path.join(ROOT, "oracle", "_ref", "bin")
 PLUGINS = os.path.join(ROOT, "smart_amd", "bin", "plugins")
-ALGOS = ["hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8", "sbndm", "kr"]
+ALGOS = ["hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8", "sbndm", "kr", "bndml"]
 
 
 @pytest.fixture(scope="module")

@@ -14,7 +14,7 @@ run sweep_english_4gib --corpus english --gib 4 --ms 2,4,8,16,32,64,256,1024,409
 run sweep_cfg5_rand2_4gib --sigma 2 --gib 4 --ms $MS_FULL --algos hor,bm,kmp,so,epsm --reps 3 &&
 run sweep_cfg5_rand32_4gib --sigma 32 --gib 4 --ms $MS_FULL --algos hor,bm,kmp,so,epsm --reps 3 &&
 run sweep_cfg5_rand256_4gib --sigma 256 --gib 4 --ms $MS_FULL --algos hor,bm,kmp,so,epsm --reps 3 &&
-F3=sa,qs,tunedbm,raita,hash3,hash5,hash8,sbndm,kr &&
+F3=sa,qs,tunedbm,raita,hash3,hash5,hash8,sbndm,kr,bndml &&
 run sweep_f3_rand128 --algos $F3 --ms 8,16,32,64,128,256,512,1024,2048,4096 --reps 3 &&
 run sweep_f3_rand4 --algos $F3 --sigma 4 --ms 8,16,32,64 --reps 3 &&
 run sweep_f3_english_4gib --algos $F3 --corpus english --gib 4 --ms 8,16,32,64,256,1024,4096 --reps 3
