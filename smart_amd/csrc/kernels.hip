@@ -1791,7 +1791,9 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_
     // POLICY 0: A non-temporal, B cached (default); 1: both cached; 3: one nt load + shuffle.
     // (Both loads nt measured 62-67 %: the second load must find the line still cached.  A
     // ballot/SGPR formulation of the first-dword test measured 59-73 %: scalar-unit bound.)
-    // Also measured and dropped (profiles/r01 session p): a sparse pre-pass (running minimum of text
+    // Also measured and dropped (profiles/r01 session p): completing the few survivors of a dword in
+    // memory instead of testing the next dword at all alignments (English 55-60 % -> 40-57 %: the
+    // cached loads stall every row), a sparse pre-pass (running minimum of text
     // dword ^ f0, 2.25 instead of 3.25 VALU ops per alignment), two steps of loads in flight in
     // registers, and capping the resident workgroups through an LDS allocation — all within noise of
     // 76-80 %; the VALU is 63 % busy, the waves wait on memory half of their time (PMC).
