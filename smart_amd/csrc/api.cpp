@@ -275,6 +275,9 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
                 std::vector<uint32_t> B(256 * W, 0u);
                 for (uint32_t i = 0; i < w; ++i) B[P[w - 1 - i] * W + i / 32] |= 1u << (i % 32);
                 append(B.data(), B.size() * 4);
+                const std::vector<int32_t> nx = sg::kmp_next(P, w);  // nx[w] = longest proper border of P[0..w)
+                const uint32_t period = w - static_cast<uint32_t>(nx[w]);
+                append(&period, 4);
                 break;
             }
             [[fallthrough]];  // m <= 32: plain BNDM (bndml.c:44-75)

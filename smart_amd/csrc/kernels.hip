@@ -719,7 +719,7 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
 // any m (its table is 128 KB at m = 4096); here a pattern longer than 256 bytes is filtered by its
 // 256-byte prefix and the rest is verified in memory, as the single-word algorithms do with 32.
 // Tiles are indexed by the END of the w-byte window with a 256-byte back halo.
-// LDS: u32 B[256][W] | text [tile0-256, tile0+TB)
+// LDS: u32 B[256][W] | P[0..w) | text [tile0-256, tile0+TB)
 // ---------------------------------------------------------------------------
 template <int THREADS, int L, int W, bool LONG>  // LONG: m > 256
 __global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a, uint64_t tile_first, uint32_t ntiles)
@@ -729,9 +729,13 @@ __global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a, uint64_t tile_
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 256 ? m : 256;
     uint32_t* B = reinterpret_cast<uint32_t*>(smem);
-    uint8_t* txt = smem + 256 * W * 4;
+    uint8_t* pw = smem + 256 * W * 4;  // P[0..w), for the direct comparison below
+    uint8_t* txt = pw + 256;
     for (uint32_t i = threadIdx.x; i < 256 * W; i += THREADS)
         B[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i];
+    for (uint32_t i = threadIdx.x; i < w; i += THREADS) pw[i] = a.blob[i];
+    // shift after an occurrence: the period of P[0..w) — what the walk below would find as w - longest
+    const uint32_t period = *reinterpret_cast<const uint32_t*>(a.blob + kTableOff + 256 * W * 4);
     const uint32_t top_word = (w - 1) >> 5, top_bit = 1u << ((w - 1) & 31u);
 
     const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
@@ -784,6 +788,39 @@ __global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a, uint64_t tile_
                 }
                 uint32_t k = 1, longest = 0;
                 while (k < w && alive != 0) {  // bndml.c:104-116
+                    if (k == 32) {
+                        // Still alive 32 bytes deep.  The walk is not continued: by ONE lane with W-word
+                        // shifts it cost ~0.26 ms per occurrence (each is surrounded by windows that stay
+                        // alive for up to w bytes).  D already says where these 32 bytes occur in P:
+                        // bit b <=> they are P[w-1-b .. w-1-b+32), i.e. P would end r = b - 31 bytes to
+                        // the right of this window.  The lowest set bit is the nearest such alignment
+                        // and a safe shift — the one the full walk arrives at, too.  r = 0 (they are P's
+                        // suffix) is settled by comparing the window with P directly.
+                        auto lowest = [&]() -> uint32_t {  // index of the lowest set bit of D, or 32*W
+                            uint32_t b = 32u * W;
+#pragma unroll
+                            for (int i = W - 1; i >= 0; --i) b = D[i] != 0 ? 32u * i + (uint32_t)__builtin_ctz(D[i]) : b;
+                            return b;
+                        };
+                        uint32_t b = lowest();
+                        if (b == 31) {
+                            uint32_t j = 0;
+                            while (j < w && txt[e - j] == pw[w - 1 - j]) ++j;
+                            if (j == w) {  // an occurrence: count it below, move on by the period
+                                k = w;
+                                longest = w - period;
+                                break;
+                            }
+#pragma unroll
+                            for (int i = 0; i < W; ++i) D[i] = i == 0 ? (D[i] & 0x7FFFFFFFu) : D[i];
+                            b = lowest();
+                        }
+                        const uint32_t r = b < 32u * W ? b - 31u : w;  // nearest remaining alignment
+                        const uint32_t sh = r < w - longest ? r : w - longest;
+                        longest = w - sh;
+                        alive = 0;
+                        break;
+                    }
                     uint32_t top = 0;
 #pragma unroll
                     for (int i = 0; i < W; ++i) top = (uint32_t)i == top_word ? D[i] : top;
@@ -2307,7 +2344,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
 #define SG_BNDML(W_)                                                                                      \
     do {                                                                                                  \
-        const size_t lds = 256 * (W_) * 4 + 256 + (size_t)kBndmT * kBndmL;                                \
+        const size_t lds = 256 * (W_) * 4 + 256 + 256 + (size_t)kBndmT * kBndmL;                          \
         if (m > 256) return launch_tiled(bndml_scan<kBndmT, kBndmL, W_, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream); \
         return launch_tiled(bndml_scan<kBndmT, kBndmL, W_, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);            \
     } while (0)
