@@ -82,8 +82,9 @@ static void usage(void)
     printf("\t-txt          write the result table as results/<code>/<corpus>.txt\n");
     printf("\t-tex          write it as a LaTeX tabular too\n");
     printf("\t-simple P T   one search of pattern P (<= 100 chars) in text T (<= 1000 chars)\n");
-    printf("\t-algo LIST    comma separated algorithms out of hor,bm,kmp,so,bndm,epsm (default: all six,\n");
-    printf("\t              or the ones marked #1 in source/algorithms.h when that file exists)\n");
+    printf("\t-algo LIST    comma separated algorithms out of hor,bm,kmp,so,bndm,epsm,sa,qs,tunedbm,raita,\n");
+    printf("\t              hash3,hash5,hash8,sbndm,kr,bndml (default: all of them, or the ones marked #1 in\n");
+    printf("\t              source/algorithms.h when that file exists)\n");
     printf("\t-data DIR     directory holding <corpus>/index.txt (default \"data\")\n");
     printf("\t-gpu D        device ordinal (default 0)\n");
     printf("\t-gpus K       shard the text by byte offset over GPUs 0..K-1 (RCCL sum of the counts)\n");
