@@ -407,6 +407,56 @@ static void write_xml(const struct options *o, const char *corpus, const char *c
     fclose(fp);
 }
 
+/* results/<code>/<corpus>.html: the report page (reference: outputHTML2, src/output.h:443-633).
+ * Same content — header block, one row per algorithm and one column per length, the best time
+ * of a column in bold, the preprocessing time when -pre was given — as a self-contained page:
+ * the reference's page draws its charts with the RGraph scripts and style sheet of its results/
+ * directory, which are not part of this project; here the GB/s of each cell are listed under the
+ * time instead. */
+static void write_html(const struct options *o, const char *corpus, const char *code, long long n,
+                       struct cell table[MAX_ALGOS][MAX_LENGTHS])
+{
+    char path[400];
+    mkdir("results", 0775);
+    snprintf(path, sizeof path, "results/%s", code);
+    mkdir(path, 0775);
+    snprintf(path, sizeof path, "results/%s/%s.html", code, corpus);
+    FILE *fp = fopen(path, "w");
+    if (!fp) return;
+    printf("\tSaving data on %s/%s.html\n", code, corpus);
+    fprintf(fp, "<!DOCTYPE html><html><head><meta charset=\"utf-8\"><title>SMART Experimental Results %s: %s</title>\n", code, corpus);
+    fprintf(fp, "<style>body{font-family:sans-serif}table{border-collapse:collapse}td{border:1px solid #999;padding:3px 8px;"
+                "text-align:center}td.algo{text-align:left}.best{font-weight:bold}.pre,.gbs{font-size:70%%;color:#666}</style>"
+                "</head><body>\n");
+    fprintf(fp, "<h2>Report of Experimental Results</h2>\n<p>Test Code %s<br>Text %s (size : %lld bytes)<br>"
+                "Engine: %s, %d GPU(s)</p>\n", code, corpus, n, smartgpu_version(), o->gpus > 1 ? o->gpus : 1);
+    fprintf(fp, "<table id=\"resultTable\">\n<tr><td></td>");
+    for (int il = 0; o->lengths[il] > 0; ++il)
+        if (o->lengths[il] >= o->minlen && o->lengths[il] <= o->maxlen) fprintf(fp, "<td>%d</td>", o->lengths[il]);
+    fprintf(fp, "</tr>\n");
+    for (int ia = 0; ia < o->nalgos; ++ia) {
+        char name[32];
+        upper(name, smartgpu_algo_name(o->algos[ia]));
+        fprintf(fp, "<tr><td class=\"algo\"><b>%s</b></td>", name);
+        for (int il = 0; o->lengths[il] > 0; ++il) {
+            if (o->lengths[il] < o->minlen || o->lengths[il] > o->maxlen) continue;
+            const struct cell *c = &table[ia][il];
+            double best = 0;
+            for (int ib = 0; ib < o->nalgos; ++ib)
+                if (table[ib][il].mean > 0 && (best == 0 || table[ib][il].mean < best)) best = table[ib][il].mean;
+            fprintf(fp, "<td>");
+            if (o->pre && c->mean > 0) fprintf(fp, "<div class=\"pre\">%.2f</div>", c->pre);
+            if (c->mean <= 0) fprintf(fp, "<div>-</div>");
+            else fprintf(fp, "<div%s>%.2f</div><div class=\"gbs\">%.1f GB/s</div>", c->mean == best ? " class=\"best\"" : "", c->mean, c->gbs);
+            fprintf(fp, "</td>");
+        }
+        fprintf(fp, "</tr>\n");
+    }
+    fprintf(fp, "</table>\n<p>Running times in milliseconds (mean over %d patterns)%s.</p></body></html>\n", o->runs,
+            o->pre ? ", preprocessing times above them" : "");
+    fclose(fp);
+}
+
 int main(int argc, char **argv)
 {
     struct options o;
@@ -556,6 +606,7 @@ int main(int argc, char **argv)
         smartgpu_mtext_free(mtext);
         if (o.txt) write_txt(&o, corpus, code, table);
         write_xml(&o, corpus, code, table); /* always, as smart.c:388 */
+        write_html(&o, corpus, code, (long long)n, table); /* always, as smart.c:389 */
         if (o.tex) write_tex(&o, corpus, code, table);
         smartgpu_text_free(text);
     }

@@ -82,6 +82,8 @@ def test_smart_report_lines(tmp_path):
     assert table and table[0].read_text().startswith("HOR")
     xml = list((tmp_path / "results").glob("EXP*/rand128.xml"))[0].read_text()
     assert xml.startswith("<RESULTS>") and xml.count("<NAME>") == 16 and "<SEARCH>" in xml and "<BEST>" in xml
+    html = list((tmp_path / "results").glob("EXP*/rand128.html"))[0].read_text()
+    assert html.startswith("<!DOCTYPE html>") and html.count("<tr><td class=\"algo\">") == 16 and "class=\"best\"" in html
     tex = list((tmp_path / "results").glob("EXP*/rand128.tex"))[0].read_text()
     assert tex.startswith("\\begin{tabular}{|l|l|}") and "\\textsc{HOR} & " in tex and tex.endswith("\\end{tabular}")
     # -simple: the reference's own example (SURVEY.md §5 hazard 3 segfaults EPSM there)
