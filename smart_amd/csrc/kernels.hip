@@ -401,11 +401,16 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
         if (lo < hi) {
             uint32_t e = (uint32_t)(lo - tile0) + kBpHB;  // P-coordinates
             const uint32_t ehi = (uint32_t)(hi - tile0) + kBpHB;
-            if (KR && kr_w == 32 && lo == seg && hi == seg + kBpL) {
-                // m >= 32 and a whole lane: the 64 window ends are this lane's own column, 16 dwords at
-                // compile-time offsets; nothing leaves the 32-bit hash, so a step is shift + add.
-                // Equal hashes are rare: a running minimum of h ^ hp says whether a group of 16 has
-                // one, and only then are its ends looked at one by one.
+            if (KR && m >= 8 && lo == seg && hi == seg + kBpL) {
+                // A whole lane: the 64 window ends are this lane's own column, 16 dwords at compile-time
+                // offsets, and the hash rolled is always the one of the last 32 bytes, from which nothing
+                // has to be subtracted: a step is shift + add.  For m >= 32 that IS the reference's hash;
+                // for m < 32 its low m bits are the low m bits of the reference's (bytes further back only
+                // reach bits >= m), so those are compared — a filter of 2^-m instead of 2^-32, exact all
+                // the same because every equal hash is confirmed byte by byte (m < 8: the rolling form
+                // with the outgoing byte below).  Equal hashes are rare: a running minimum of the masked
+                // difference says whether a group of 16 has one, and only then are its ends looked at.
+                const uint32_t kr_mask = kr_w == 32 ? 0xFFFFFFFFu : (1u << kr_w) - 1u;
                 uint32_t h = 0;
                 for (uint32_t k = 1; k <= 32; ++k) h += (uint32_t)txt[bp_addr(e - k)] << (k - 1);  // window ending at e-1
                 const uint8_t* col = txt + (kBpHaloCols + tid) * 4u;
@@ -418,14 +423,14 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         h = (h << 1) + ((d[i >> 2] >> (8 * (i & 3))) & 0xFFu);  // kr.c:26,48
-                        near = min(near, h ^ kr_hp);
+                        near = min(near, (h ^ kr_hp) & kr_mask);
                     }
                     if (near == 0) {  // kr.c:47: some end in this group has the pattern's hash: confirm
                         uint32_t hh = h0;
                         for (uint32_t i = 0; i < 16; ++i) {
                             const uint32_t ee = e + 16 * g + i;
                             hh = (hh << 1) + txt[bp_addr(ee)];
-                            if (hh != kr_hp) continue;
+                            if (((hh ^ kr_hp) & kr_mask) != 0) continue;
                             uint32_t k = 0;
                             while (k <= H && ptail[H - k] == txt[bp_addr(ee - k)]) ++k;
                             bool ok = k == H + 1;
