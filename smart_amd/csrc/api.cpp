@@ -107,6 +107,7 @@ struct smartgpu_plan {
     uint32_t halo = 0;
     uint32_t prefer_packed = 0;  // see build_blob
     uint32_t sparse = 0;         // see build_blob
+    uint32_t so_off = 0;         // see build_blob
     uint8_t* blob = nullptr;               // device: pattern + tables
     unsigned long long* results = nullptr; // device: kResultSlots counters (library-owned)
     unsigned long long* ext_results = nullptr; // caller-owned device buffer, if set
@@ -157,10 +158,11 @@ smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
 
 // Build the device blob (pattern + tables) for (algo, P, m) in a host vector.
 std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t* halo,
-                                uint32_t* prefer_packed, uint32_t* sparse)
+                                uint32_t* prefer_packed, uint32_t* sparse, uint32_t* so_off)
 {
     *prefer_packed = 0;
     *sparse = 0;
+    *so_off = 0;
     std::vector<uint8_t> blob(sg::kPatternBytes, 0);
     std::memcpy(blob.data(), P, m);
     auto append = [&blob](const void* p, size_t bytes) {
@@ -178,18 +180,24 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         }
         append(fp, sizeof fp);
     };
-    // Mean bad-character shift E if the text's symbols are distributed like the pattern's
-    // own.  A pattern over a large alphabet has E ~ m/2; E well below that (and below ~12
-    // bytes) means repeated symbols — binary/DNA-like alphabets, natural language — where a
-    // skip loop verifies windows all the time and lanes diverge, and the packed matcher is
-    // the better regime (measured on rand2/rand4/English).  The count does
-    // not depend on the choice.
-    auto tiny_shifts = [&](const std::vector<int32_t>& bc) {
-        uint64_t sum = 0;
-        for (uint32_t i = 0; i < m; ++i) sum += static_cast<uint64_t>(bc[P[i]]);
-        const double e = static_cast<double>(sum) / m;
-        return m > 7 && e < std::min(0.4 * m, 12.0);
-    };
+    // How often two text symbols are equal, if the text's symbols are distributed like the pattern's
+    // own (unbiased from its histogram: sum c(c-1) / m(m-1)).  Above 1/48 — binary and DNA-like
+    // alphabets, natural language (~1/15), rand32 — a skip loop meets a candidate every few windows,
+    // its lanes verify and diverge (English, m >= 64: BM 31-44 %, BNDM 31-36 %, HOR 63-69 %; rand32:
+    // 67-75 %), and the packed matcher, which does the same work whatever the bytes are, is the better
+    // regime (64-81 % on all of them).  Below it (rand64 and up) windows die on their first comparison
+    // and the skip kernels only stream (80-86 % on rand128 against 76-81 %).  Measured: DESIGN.md §8.
+    // The count does not depend on the choice.
+    bool repeats = false;
+    {
+        uint32_t cnt[256] = {0};
+        for (uint32_t i = 0; i < m; ++i) ++cnt[P[i]];
+        uint64_t pairs = 0;
+        for (uint32_t c = 0; c < 256; ++c) pairs += static_cast<uint64_t>(cnt[c]) * (cnt[c] > 0 ? cnt[c] - 1 : 0);
+        // m < 32: too few symbols for the estimate; two equal pairs are taken as a sign (rand32, m = 16:
+        // skip kernels 58-65 %, packed 76 %; on rand128 one pattern in four then goes packed, 76 % for 83 %)
+        repeats = m > 7 && (pairs * 48 > static_cast<uint64_t>(m) * (m - 1) || (m < 32 && pairs >= 4));
+    }
     // The opposite case: hardly any symbol of the pattern repeats (random text over a large
     // alphabet).  Windows then die on their first comparison and a skip kernel only streams; it
     // runs best with FEWER workgroups per CU (kTileWgs in kernels.hip, measured).  Natural
@@ -218,7 +226,7 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             for (int c = 0; c < 256; ++c) tab8[c] = static_cast<uint8_t>(bc[c] > 255 ? 255 : bc[c]);
             append(tab8, 256);
             append_fingerprint();  // packed regime
-            *prefer_packed = tiny_shifts(bc);
+            *prefer_packed = repeats;
             break;
         }
         case SMARTGPU_BM: {
@@ -242,7 +250,7 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             append(tab.data(), tab.size() * 2);
             if (blob.size() % 4) blob.resize((blob.size() + 3) & ~size_t(3), 0);
             append_fingerprint();  // packed regime
-            *prefer_packed = tiny_shifts(bc);
+            *prefer_packed = repeats;
             break;
         }
         case SMARTGPU_KMP: {
@@ -278,6 +286,8 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
                 const std::vector<int32_t> nx = sg::kmp_next(P, w);  // nx[w] = longest proper border of P[0..w)
                 const uint32_t period = w - static_cast<uint32_t>(nx[w]);
                 append(&period, 4);
+                append_fingerprint();  // packed regime (at kTableOff + 1024*W + 4)
+                *prefer_packed = repeats;
                 break;
             }
             [[fallthrough]];  // m <= 32: plain BNDM (bndml.c:44-75)
@@ -292,7 +302,7 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
                 const uint32_t period = w - static_cast<uint32_t>(nx[w]);
                 append(&period, 4);
             }
-            *prefer_packed = tiny_shifts(sg::bad_char(P, m));
+            *prefer_packed = repeats;
             break;
         }
         case SMARTGPU_EPSM:
@@ -323,7 +333,7 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             const uint8_t spare[256] = {0};
             append(spare, 256);
             append_fingerprint();  // packed regime
-            *prefer_packed = tiny_shifts(sg::bad_char(P, m));
+            *prefer_packed = repeats;
             break;
         }
         case SMARTGPU_QS: {  // same layout as HOR: u16 table, 256 spare bytes, fingerprint
@@ -334,8 +344,26 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             const uint8_t spare[256] = {0};
             append(spare, 256);
             append_fingerprint();  // packed regime
-            *prefer_packed = tiny_shifts(sg::bad_char(P, m));
+            *prefer_packed = repeats;
             break;
+        }
+    }
+    // A pattern of 16+ bytes whose first dword says next to nothing about where it occurs (two or
+    // three symbols: every lane of the packed matcher keeps a candidate through all four fingerprint
+    // dwords, every skip is a byte or two) is counted by the Shift-Or runs kernel, which does the
+    // same work whatever the bytes are (kernels.hip launch_scan): append its masks.  The estimate is
+    // the chance that 4 text bytes drawn like the pattern's own equal P[0..4), times the 16
+    // alignments a lane tests.  KMP, SO, SA and KR keep their own serial kernels.
+    if (m >= 16 && algo != SMARTGPU_KMP && algo != SMARTGPU_SO && algo != SMARTGPU_SA && algo != SMARTGPU_KR) {
+        uint32_t cnt[256] = {0};
+        for (uint32_t i = 0; i < m; ++i) ++cnt[P[i]];
+        double pass = 16.0;
+        for (uint32_t i = 0; i < 4; ++i) pass *= static_cast<double>(cnt[P[i]]) / m;
+        if (pass >= 0.15) {  // rand2: 1.0, rand3: 0.2 (so_runs 63-68 % vs 54-63 %), rand4: 0.06 (no difference measured)
+            blob.resize((blob.size() + 15) & ~size_t(15), 0);
+            *so_off = static_cast<uint32_t>(blob.size());
+            const std::vector<uint32_t> S = sg::shift_or_masks(P, m);
+            append(S.data(), 1024);
         }
     }
     blob.resize((blob.size() + 255) & ~size_t(255), 0);
@@ -365,6 +393,7 @@ sg::ScanArgs make_args(const smartgpu_plan* p, const smartgpu_text* text, uint64
     a.fp_off = 0;
     a.prefer_packed = p->prefer_packed;
     a.sparse = p->sparse;
+    a.so_off = p->so_off;
     a.blob = p->blob;
     a.count = p->slot_ptr(slot);
     return a;
@@ -503,7 +532,7 @@ smartgpu_plan* smartgpu_plan_create(int algo, const uint8_t* P, uint32_t m, int 
     p->device = device;
     p->algo = algo;
     p->m = m;
-    const std::vector<uint8_t> blob = build_blob(algo, P, m, &p->halo, &p->prefer_packed, &p->sparse);
+    const std::vector<uint8_t> blob = build_blob(algo, P, m, &p->halo, &p->prefer_packed, &p->sparse, &p->so_off);
     bool ok = hipMalloc(reinterpret_cast<void**>(&p->blob), blob.size()) == hipSuccess &&
               hipMalloc(reinterpret_cast<void**>(&p->results), sizeof(unsigned long long) * sg::kResultSlots) == hipSuccess;
     if (ok) {
@@ -579,7 +608,7 @@ int smartgpu_plan_result(smartgpu_plan* p, int slot, uint64_t* count, double* ke
 
 const char* smartgpu_plan_kernel_name(const smartgpu_plan* p)
 {
-    return p ? sg::scan_kernel_name(p->algo, p->m, p->prefer_packed != 0) : nullptr;
+    return p ? sg::scan_kernel_name(p->algo, p->m, p->prefer_packed != 0, p->so_off != 0) : nullptr;
 }
 
 void* smartgpu_plan_result_device_ptr(smartgpu_plan* p) { return p ? p->slot_ptr(0) : nullptr; }

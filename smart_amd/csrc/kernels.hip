@@ -1497,7 +1497,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
     {   // expand the 256 masks to one copy per lane through a 1 KB staging area (wave 0's slab):
         // one global load per thread instead of 16 dependent broadcast loads
         uint32_t* stage = reinterpret_cast<uint32_t*>(smem + 65536);
-        if (threadIdx.x < 256) stage[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[threadIdx.x] << (32 - w);
+        if (threadIdx.x < 256) stage[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.blob + a.so_off)[threadIdx.x] << (32 - w);
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < 256 * 64; i += kRunWaves * 64) S[i] = stage[i >> 6];
     }
@@ -2108,8 +2108,9 @@ constexpr int kEpsmT = 256;
 
 static int hor_regime(uint32_t m, int algo = SMARTGPU_HOR);
 
-const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
+const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_masks)
 {
+    if (so_masks && g_tune[0] == 0) return "so_runs";
     const bool pk = prefer_packed && g_tune[0] == 0;
     switch (algo) {
         case SMARTGPU_TUNEDBM:
@@ -2128,7 +2129,7 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed)
         case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : "kmp_runs";
         case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : "so_runs";
         case SMARTGPU_BNDML:
-            if (m > 32) return "bndml_scan";
+            if (m > 32) return pk ? "packed_scan" : "bndml_scan";
             [[fallthrough]];
         case SMARTGPU_SBNDM:
         case SMARTGPU_BNDM: return (pk || (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1)) ? "packed_scan" : "bndm_scan";
@@ -2154,6 +2155,31 @@ static uint64_t balanced_run_len(uint64_t s_begin, uint64_t s_end, uint64_t per_
     if (L < lmin) return (lmin + 63) & ~63ull;
     while (tiles_for(s_begin, s_end, L).count > slots * k) L += 64;
     return L;
+}
+
+// Shift-Or / Shift-And runs (so_runs); the masks u32 S[256] sit at a.blob + a.so_off.
+static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus, hipStream_t stream)
+{
+    // bank-private table: 64 KB shared by the 16 waves of ONE workgroup per CU
+    const uint32_t m = a.m;
+    const uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
+    const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin);
+    const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
+    if (tr.count == 0) return hipSuccess;
+    const size_t lds = 65536 + kRunWaves * (size_t)kLineSlab;
+    uint64_t grid = ((uint64_t)tr.count + 64ull * kRunWaves - 1) / (64ull * kRunWaves);
+    if (grid > (uint64_t)num_cus) grid = num_cus;
+#define SG_SO_RUNS(L_, A_)                                                                               \
+    do {                                                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(so_runs<L_, A_>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        hipLaunchKernelGGL((so_runs<L_, A_>), dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, \
+                           (uint32_t)L, (uint64_t)tr.count);                                             \
+    } while (0)
+    if (shift_and) { if (m > 32) SG_SO_RUNS(true, true); else SG_SO_RUNS(false, true); }
+    else { if (m > 32) SG_SO_RUNS(true, false); else SG_SO_RUNS(false, false); }
+#undef SG_SO_RUNS
+    return hipGetLastError();
 }
 
 static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream)
@@ -2278,6 +2304,12 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
 {
     if (a.s_end <= a.s_begin) return hipSuccess;
     const uint32_t m = a.m;
+    // A pattern over two or three symbols, 16 bytes or longer: no byte, pair or dword of it tells a
+    // window from its neighbours, so the skip kernels move one or two bytes at a time and the packed
+    // matcher tests all four fingerprint dwords at every alignment (33-45 % on rand2, all of them).
+    // The branch-free bit-parallel runs kernel does not care what the bytes are (66-70 %): plans of
+    // such patterns carry Shift-Or masks as well (api.cpp build_blob) and count with it.
+    if (a.so_off != 0 && g_tune[0] == 0) return launch_so_runs(a, false, num_cus, stream);
     switch (algo) {
         case SMARTGPU_TUNEDBM:  // hor_scan<.., 0> is Tuned BM's loop (see the kernel's comment)
         case SMARTGPU_HOR: {
@@ -2346,6 +2378,11 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
         case SMARTGPU_BNDML:
             if (m > 32) {  // multi-word vectors; m <= 32 is plain BNDM (bndml.c:44-75): falls through
                 const uint32_t w = m < 256 ? m : 256;
+                if (a.prefer_packed && g_tune[0] == 0) {
+                    ScanArgs b = a;
+                    b.fp_off = kTableOff + 1024 * (w <= 64 ? 2 : w <= 128 ? 4 : 8) + 4;  // after the masks and the period
+                    return launch_packed<SMARTGPU_BNDM>(b, num_cus, stream);
+                }
                 const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
 #define SG_BNDML(W_)                                                                                      \
     do {                                                                                                  \
@@ -2397,25 +2434,9 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 return hipGetLastError();
             }
             if (g_tune[6] != 1 || algo == SMARTGPU_SA) {  // per-lane runs through LDS line slabs (tune[6]=1: LDS tiles, for A/B)
-                // bank-private table: 64 KB shared by the 16 waves of ONE workgroup per CU
-                const uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
-                const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin);
-                const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
-                if (tr.count == 0) return hipSuccess;
-                const size_t lds = 65536 + kRunWaves * (size_t)kLineSlab;
-                uint64_t grid = ((uint64_t)tr.count + 64ull * kRunWaves - 1) / (64ull * kRunWaves);
-                if (grid > (uint64_t)num_cus) grid = num_cus;
-#define SG_SO_RUNS(L_, A_)                                                                               \
-    do {                                                                                                 \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(so_runs<L_, A_>),                        \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-        hipLaunchKernelGGL((so_runs<L_, A_>), dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, \
-                           (uint32_t)L, (uint64_t)tr.count);                                             \
-    } while (0)
-                if (algo == SMARTGPU_SA) { if (m > 32) SG_SO_RUNS(true, true); else SG_SO_RUNS(false, true); }
-                else { if (m > 32) SG_SO_RUNS(true, false); else SG_SO_RUNS(false, false); }
-#undef SG_SO_RUNS
-                return hipGetLastError();
+                ScanArgs b = a;
+                b.so_off = kTableOff;
+                return launch_so_runs(b, algo == SMARTGPU_SA, num_cus, stream);
             }
             const size_t lds = 1040 + (size_t)kSoT * kSoL + 32;
             const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kSoT * kSoL);

@@ -32,6 +32,8 @@ struct ScanArgs {
     uint32_t prefer_packed;     // HOR/BM: the shift tables promise tiny shifts (small alphabet) -> packed regime
     uint32_t sparse;            // skip kernels: the pattern's own symbols promise long shifts and few candidates
                                 // (api.cpp build_blob) -> fewer workgroups per CU, see kTileWgs
+    uint32_t so_off;            // blob offset of Shift-Or masks u32 S[256]; set by launch_scan for SO/SA, by the plan
+                                // for other algorithms when the pattern is best counted by so_runs (else 0)
     const uint8_t* blob;        // device: [pattern kPatternBytes][tables ...]
     unsigned long long* count;  // device result slot (pre-zeroed)
 };
@@ -56,7 +58,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
 // (unordered, at most `cap` entries), total in a.count; the blob must be an EPSM blob
 hipError_t launch_find(const ScanArgs& a, unsigned long long* out, unsigned long long cap, int num_cus,
                        hipStream_t stream);
-const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed);
+const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_masks);
 
 // tuning knobs (smartgpu_tune): [0] HOR variant 0 auto / 1 flat / 2 bank-private
 extern int g_tune[8];

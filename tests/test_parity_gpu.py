@@ -285,6 +285,43 @@ def test_small_alphabets_dense_matches(oracle):
                 assert got[a] == want, (a, sigma, m, got, want)
 
 
+def test_two_symbol_patterns_count_on_shift_or_runs_and_on_their_own_kernels(oracle):
+    """A pattern of 16+ bytes over two or three symbols is counted by so_runs whatever the algorithm
+    (api.cpp build_blob / kernels.hip launch_scan); tune(0,1) keeps every algorithm on its own kernel.
+    Both must give the oracle's count; patterns over larger alphabets are not rerouted."""
+    from smart_amd import engine
+    own = ("kmp", "kr")
+    for sigma, n in ((2, 1_500_000), (3, 1_000_003)):
+        T = oracle.gen_text(977 + sigma, sigma, 0, n)
+        text = Text.upload(T)
+        for m in (16, 17, 31, 32, 33, 64, 100, 300, 4096):
+            for P in (T[4321:4321 + m].copy(), np.resize(T[9:11], m)):
+                want = oracle.search("hor", P, T)
+                for a in ALGOS:
+                    if len(set(P.tolist())) > 2 or not applies(a, m):
+                        continue
+                    pl = Plan(a, P)
+                    assert (pl.kernel_name == "so_runs") == (a not in own), (a, m, pl.kernel_name)
+                    pl.free()
+                got = gpu_counts(P, text)
+                assert all(v == want for v in got.values()), (sigma, m, got, want)
+                engine.tune(0, 1)
+                try:
+                    pl = Plan("bm", P)
+                    assert pl.kernel_name == "bm_scan"
+                    pl.free()
+                    got = gpu_counts(P, text)
+                finally:
+                    engine.tune(0, 0)
+                assert all(v == want for v in got.values()), ("own kernels", sigma, m, got, want)
+        text.free()
+    T = oracle.gen_text(5, 128, 0, 100_000)
+    for a in ("hor", "bm", "bndm", "epsm", "qs"):
+        pl = Plan(a, T[50:82])
+        assert pl.kernel_name != "so_runs", a
+        pl.free()
+
+
 def test_device_generator_matches_oracle(oracle):
     for sigma, off, n in ((128, 0, 100000), (2, 12345, 70001), (250, 7, 4099), (256, 8, 64), (4, 3, 1)):
         text = Text.generate(SEED2, sigma, n, off=off)
