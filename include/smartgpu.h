@@ -195,8 +195,10 @@ int smartgpu_probe_read_ms(const smartgpu_text *t, int reps, double *ms_per_pass
 
 /* Kernel-variant selection for experiments and A/B measurements (not needed in normal use;
  * every variant is parity-tested).  Keys:
- *   0  regime of the skip algorithms: 0 auto / 1 always the LDS-tile skip loop / 2 Horspool's
- *      bank-private LDS layout / 3 always the packed matcher
+ *   0  regime of the skip algorithms: 0 auto — short patterns and patterns whose symbols repeat on
+ *      the packed matcher, patterns of 16+ bytes over two or three symbols on so_runs, the rest on
+ *      the algorithm's own LDS-tile skip loop / 1 always the algorithm's own skip
+ *      loop / 2 Horspool's bank-private LDS layout / 3 always the packed matcher
  *   3  KMP: 0 kmp_runs (transition table) / 1 kmp_scan (LDS tiles, m <= 40) / 2 kmp_links_runs
  *      (failure links followed per byte)
  *   5  run length in bytes of the runs kernels (so_runs, kmp_runs); 0 = default

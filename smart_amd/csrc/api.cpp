@@ -198,20 +198,14 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         // skip kernels 58-65 %, packed 76 %; on rand128 one pattern in four then goes packed, 76 % for 83 %)
         repeats = m > 7 && (pairs * 48 > static_cast<uint64_t>(m) * (m - 1) || (m < 32 && pairs >= 4));
     }
-    // The opposite case: hardly any symbol of the pattern repeats (random text over a large
-    // alphabet).  Windows then die on their first comparison and a skip kernel only streams; it
-    // runs best with FEWER workgroups per CU (kTileWgs in kernels.hip, measured).  Natural
-    // language and small alphabets repeat symbols and keep the lanes busy verifying: more
-    // workgroups hide that.  The count does not depend on the choice.
-    {
-        uint32_t distinct = 0;
-        bool seen[256] = {false};
-        for (uint32_t i = 0; i < m; ++i)
-            if (!seen[P[i]]) { seen[P[i]] = true; ++distinct; }
-        // >= 80 % of the min(m,64) possible, and windows long enough for long shifts (m = 8: 61 % with
-        // four workgroups per CU against 75 % with eight)
-        *sparse = m >= 16 && distinct * 10 >= std::min<uint32_t>(m, 64) * 8;
-    }
+    // The opposite case: symbols do not repeat (random text over a large alphabet).  Windows then die on
+    // their first comparison and a skip kernel only streams; it runs best with FEWER workgroups per CU
+    // (kTileWgs in kernels.hip, measured).  Patterns with repeating symbols that still run on a tile
+    // kernel (tune(0,1), KR) keep the lanes busy verifying: more workgroups hide that.  Windows must be
+    // long enough for long shifts (m = 8: 61 % with four workgroups per CU against 75 % with eight).
+    // (An earlier form — >= 80 % of the first min(m,64) symbols distinct — missed rand128 at m = 64,
+    // 50 distinct symbols expected: HOR 80 %, BM 76 %, BNDM 71 % there against 84-87 % at m = 32 and 128.)
+    *sparse = m >= 16 && !repeats;
     *halo = std::min<uint32_t>(m - 1, sg::kHaloMax);
     switch (algo) {
         case SMARTGPU_TUNEDBM:  // tunedbm.c:38-40: the same table with a zero for P[m-1] — the flag bit below

@@ -683,12 +683,19 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
                     }
                     continue;
                 }
-                int i = (int)w - 2;  // bytes still to read, minus one
+                // bndm.c:49-58: D != 0 <=> the k bytes read so far are a factor of P[0..w); its top bit
+                // <=> they are a PREFIX of it, and the window may only move up to the longest such one.
+                // The loop is kept as small as Simplified BNDM's: an occurrence is handled after it.
                 uint32_t last = w, k = 1;
-                for (;;) {  // here D != 0 after k bytes
-                    if (i >= 0) {
-                        last = (uint32_t)i + 1;
-                    } else if (!LONG) {
+                for (;;) {
+                    if ((int32_t)D < 0 && k < w) last = w - k;
+                    if (k == w) break;  // the whole window is read and D != 0: an occurrence
+                    D = (D << 1) & B[txt[e - k]];
+                    if (D == 0) break;
+                    ++k;
+                }
+                if (D != 0) {
+                    if (!LONG) {
                         ++hits;
                     } else {
                         // prefix of 32 matched: verify P[32..m) (bndm.c:99-102),
@@ -701,12 +708,6 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
                             hits += global_equal(rest, a.blob + w, m - w);
                         }
                     }
-                    D <<= 1;
-                    if (i < 0 || D == 0) break;
-                    D &= B[txt[e - k]];
-                    ++k;
-                    --i;
-                    if (D == 0) break;
                 }
                 e += last;
             }
