@@ -25,6 +25,7 @@
 #include <sys/ipc.h>
 #include <sys/shm.h>
 #include <sys/types.h>
+#include <unistd.h>
 
 #include "smartgpu.h"
 
@@ -66,7 +67,12 @@ int main(int argc, char **argv)
         *pre_time = pre_ms;   /* END_PREPROCESSING, main.h:30 */
         *run_time = run_ms;   /* END_SEARCHING,     main.h:31 */
         *result = (int)count; /* main.h:120 */
-        return 0;
+        /* The answer is in the harness's memory: leave without running the HIP runtime's exit handlers
+         * (hundreds of these processes are spawned per run, the teardown is the slower half of each and
+         * has no effect on a process that is going away). */
+        shmdt(p); shmdt(t); shmdt(result); shmdt(run_time); shmdt(pre_time);
+        fflush(NULL);
+        _exit(0);
     }
     if (argc < 5) {
         printf("error in input parameter\nfour parameters needed in standard mode\n");
