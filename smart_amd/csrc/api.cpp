@@ -257,10 +257,15 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
                 const uint32_t w = std::min<uint32_t>(m, sg::kKmpDfaMaxM);
                 blob.resize((blob.size() + 15) & ~size_t(15), 0);
                 const std::vector<uint8_t> dfa = sg::kmp_dfa(P, w);
-                // row s is stored XOR-swizzled by s (kmp_delta in kernels.hip: LDS bank spread)
-                std::vector<uint8_t> sw(dfa.size());
-                for (uint32_t st = 0; st <= w; ++st)
-                    for (uint32_t c = 0; c < 256; ++c) sw[st * 256 + (c ^ st)] = dfa[st * 256 + c];
+                // State s becomes row id(s) = rotl8(s, 2), the accept state w row 255 (no other state maps
+                // there: rotl8(s, 2) = 255 only for s = 255); row r is stored XOR-swizzled by r.  Why:
+                // kmp_runs in kernels.hip (LDS bank spread on small alphabets, accept = largest id).
+                auto id = [w](uint32_t st) { return st == w ? 255u : ((st << 2) | (st >> 6)) & 255u; };
+                std::vector<uint8_t> sw(256 * 256, 0);
+                for (uint32_t st = 0; st <= w; ++st) {
+                    const uint32_t r = id(st);
+                    for (uint32_t c = 0; c < 256; ++c) sw[r * 256 + (c ^ r)] = static_cast<uint8_t>(id(dfa[st * 256 + c]));
+                }
                 append(sw.data(), sw.size());
             }
             break;

@@ -1256,8 +1256,14 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t w = PREFIX ? kKmpDfaMaxM : m;  // length the automaton recognises = accept state
-    const uint32_t table_bytes = (w + 1) * 256;
+    const uint32_t w = PREFIX ? kKmpDfaMaxM : m;  // length the automaton recognises
+    // States are renumbered on the host (api.cpp build_blob): state s is row rotl8(s, 2), the accept state
+    // row 255 — the largest id, which the running maximum needs.  A row's entries are XOR-swizzled by the
+    // row id, so a lookup's LDS bank is ((c ^ id) >> 2) & 31: with ids 0, 4, 8, ... the states a lane is
+    // usually in (the low ones) sit on different banks even when c is one of two values.  Numbered 0..w
+    // they shared banks 0 and 1 there (rand2: 49-53 % of 8 TB/s, rand4: 55-60 %).
+    constexpr uint32_t acc = 255;
+    constexpr uint32_t table_bytes = 256 * 256;
     const RunIo io = run_io(smem + table_bytes + wave * kLineSlab, lane, run_len);
     {
         const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
@@ -1310,13 +1316,13 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t 
                 const uint32_t j = jb + 16u * q;
                 if (!PREFIX) {
                     const uint32_t h0 = hits;
-                    if (whole) kmp_dfa_chunk<false, false>(v, j, j0, jend, st, hits, w);
-                    else if (j < jend && j + 16 > j0) kmp_dfa_chunk<true, false>(v, j, j0, jend, st, hits, w);
+                    if (whole) kmp_dfa_chunk<false, false>(v, j, j0, jend, st, hits, acc);
+                    else if (j < jend && j + 16 > j0) kmp_dfa_chunk<true, false>(v, j, j0, jend, st, hits, acc);
                     return hits != h0;
                 } else {
                     uint32_t hm = 0;
-                    if (whole) kmp_dfa_chunk<false, true>(v, j, j0, jend, st, hm, w);
-                    else if (j < jend && j + 16 > j0) kmp_dfa_chunk<true, true>(v, j, j0, jend, st, hm, w);
+                    if (whole) kmp_dfa_chunk<false, true>(v, j, j0, jend, st, hm, acc);
+                    else if (j < jend && j + 16 > j0) kmp_dfa_chunk<true, true>(v, j, j0, jend, st, hm, acc);
                     const bool seen = hm != 0;
                     while (hm) {  // the prefix ends at byte j+b: verify P[255..m)
                         const uint32_t b = __builtin_ctz(hm);
@@ -1345,7 +1351,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t 
                     }
                     // chunks that reached the accept state are walked again, counting (one copy of
                     // that code: the chunk index is a run-time value)
-                    uint32_t todo = (mx[0] == w ? 1u : 0u) | (mx[1] == w ? 2u : 0u) | (mx[2] == w ? 4u : 0u) | (mx[3] == w ? 8u : 0u);
+                    uint32_t todo = (mx[0] == acc ? 1u : 0u) | (mx[1] == acc ? 2u : 0u) | (mx[2] == acc ? 4u : 0u) | (mx[3] == acc ? 8u : 0u);
                     seen = todo != 0;
 #pragma unroll 1
                     while (todo) {
@@ -2208,7 +2214,7 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
         return hipGetLastError();
     }
     // one 1024-thread workgroup per CU shares the table (<= 64 KB) next to 16 x 4 KB of slabs
-    const size_t lds = (size_t)(w + 1) * 256 + kRunWaves * (size_t)kLineSlab;
+    const size_t lds = 256 * 256 + kRunWaves * (size_t)kLineSlab;  // all 256 rows: state ids are spread over them (kmp_runs)
     // runs of 2-4 KiB: at least 8x the w-1 bytes a run re-scans, at most 8 KiB (the loader's
     // over-read past the last run stays inside the text's back pad)
     uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
