@@ -226,21 +226,26 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         case SMARTGPU_BM: {
             const std::vector<int32_t> bc = sg::bad_char(P, m);
             const std::vector<int32_t> gs = sg::good_suffix(P, m);
-            std::vector<uint16_t> tab(512 + m + 1);
+            std::vector<uint16_t> tab(768 + m + 1);
             for (int c = 0; c < 256; ++c) {
                 // shift after a mismatch on the window's last byte (bm.c:89 with i = m-1), or the
                 // "last byte matches" flag
                 tab[c] = c == P[m - 1] ? 0x8000u : static_cast<uint16_t>(std::max(gs[m - 1], bc[c]));
-                tab[256 + c] = static_cast<uint16_t>(bc[c]);
+                // the same for the byte before it (bm.c:89 with i = m-2: max(bmGs[m-2], bmBc[c] - 1)):
+                // most windows that survive their last byte die here, and the kernel has this byte
+                // in hand already.  m = 1 has no such byte: all flags, the walk finds nothing to do.
+                tab[256 + c] = (m < 2 || c == P[m - 2]) ? 0x8000u
+                                                        : static_cast<uint16_t>(std::max(gs[m - 2], bc[c] - 1));
+                tab[512 + c] = static_cast<uint16_t>(bc[c]);
             }
-            for (uint32_t i = 0; i < m; ++i) tab[512 + i] = static_cast<uint16_t>(gs[i]);
+            for (uint32_t i = 0; i < m; ++i) tab[768 + i] = static_cast<uint16_t>(gs[i]);
             // gs[m]: a shift that is safe for a window whose last H+1 bytes matched, whatever
             // the remaining comparison says: min of gs over the unchecked positions (and gs[0],
             // the shift after a full match).  Used when the kernel parks the window.
             int32_t safe = gs[0];
             if (m - 1 > *halo)
                 for (uint32_t i = 0; i + 1 < m - *halo; ++i) safe = std::min(safe, gs[i]);
-            tab[512 + m] = static_cast<uint16_t>(safe);
+            tab[768 + m] = static_cast<uint16_t>(safe);
             append(tab.data(), tab.size() * 2);
             if (blob.size() % 4) blob.resize((blob.size() + 3) & ~size_t(3), 0);
             append_fingerprint();  // packed regime

@@ -241,6 +241,9 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
                     ent = tab[h & 0xFFu];
                 } else {
                     ent = VAR == 2 ? tab[txt[e + 1]] : tab[txt[e]];
+                    // (bm_scan's trick — reading the byte before the last along with it, so that a window
+                    // that dies there costs no walk — measured here: m >= 32 unchanged, m = 8..16 74-84 % ->
+                    // 48-74 %: this loop is LDS-bound at small m and the flat tile's byte reads conflict.)
                 }
                 if (VAR == 2 ? txt[e] == plast : (ent & 0x8000u) != 0) {
                     uint32_t k = VAR >= 3 ? 0 : 1;  // bytes matched so far, right to left (a hash proves nothing)
@@ -487,13 +490,18 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
     // 0x8000 when c == P[m-1]: like Horspool, a window that dies on its last byte (almost
     // all of them on large alphabets) costs one text read and one table read
     uint16_t* first = reinterpret_cast<uint16_t*>(smem);
-    uint16_t* bc = first + 256;
+    // second[c]: the same for the byte before the last, max(gs[m-2], bc[c] - 1) or the flag: the byte is
+    // read together with the last one, so a window that dies there (nearly all that survive the last
+    // byte) costs one more table read instead of a walk step plus the gs and bc reads (78-82 % -> see
+    // DESIGN.md §8)
+    uint16_t* second = first + 256;
+    uint16_t* bc = second + 256;
     uint16_t* gs = bc + 256;
-    uint8_t* ptail = smem + 1024 + round16(2 * (m + 1));
+    uint8_t* ptail = smem + 1536 + round16(2 * (m + 1));
     uint8_t* txt = ptail + round16(H + 1);
 
     const uint16_t* gtab = reinterpret_cast<const uint16_t*>(a.blob + kTableOff);
-    for (uint32_t i = threadIdx.x; i < 512 + m + 1; i += THREADS) first[i] = gtab[i];  // first, bc, gs[0..m-1], safe shift
+    for (uint32_t i = threadIdx.x; i < 768 + m + 1; i += THREADS) first[i] = gtab[i];  // first, second, bc, gs[0..m-1], safe shift
     for (uint32_t i = threadIdx.x; i <= H; i += THREADS) ptail[i] = a.blob[m - 1 - H + i];
 
     const uint64_t e_begin = a.s_begin + m - 1, e_end = a.s_end + m - 1;
@@ -536,12 +544,18 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
             while (e < ehi) {
                 // right-to-left comparison (bm.c:83); k = bytes matched
                 uint32_t c = txt[e];
+                const uint32_t c1 = txt[e - 1];  // m = 1 at the tile's first byte: a byte of ptail's padding, unused
                 const uint32_t ent = first[c];
                 if (!(ent & 0x8000u)) {  // mismatch on the last byte: bm.c:89 with i = m-1
                     e += ent;
                     continue;
                 }
-                uint32_t k = 1;
+                const uint32_t ent1 = second[c1];
+                if (!(ent1 & 0x8000u)) {  // ... on the byte before it: i = m-2
+                    e += ent1;
+                    continue;
+                }
+                uint32_t k = 2;
                 bool mismatch = false;
                 while (k <= H) {
                     c = txt[e - k];
@@ -2372,11 +2386,11 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
         case SMARTGPU_BM: {
             if ((m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
                 ScanArgs b = a;
-                b.fp_off = kTableOff + ((1024 + 2 * (m + 1) + 3) & ~3u);  // after first, bc, gs, safe shift
+                b.fp_off = kTableOff + ((1536 + 2 * (m + 1) + 3) & ~3u);  // after first, second, bc, gs, safe shift
                 return launch_packed<SMARTGPU_BM>(b, num_cus, stream);
             }
             const uint32_t H = a.halo;
-            const size_t lds = 1024 + r16(2 * (m + 1)) + r16(H + 1) + r16(H) + (size_t)kBmT * kBmL;
+            const size_t lds = 1536 + r16(2 * (m + 1)) + r16(H + 1) + r16(H) + (size_t)kBmT * kBmL;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmT * kBmL);
             const int wgs = tile_wgs(a);
             if (m - 1 > H) return launch_tiled(bm_scan<kBmT, kBmL, true>, a, tr, kBmT, lds, wgs, num_cus, stream);

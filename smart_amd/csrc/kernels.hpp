@@ -40,7 +40,7 @@ struct ScanArgs {
 
 // Byte offsets of the tables inside the blob, after the pattern slot.
 //  HOR : u16 tab[256]   shift | 0x8000 if c == P[m-1]; u8 tab8[256]; fingerprint (as EPSM)
-//  BM  : u16 first[256] (last-byte shift | 0x8000 if c == P[m-1]), u16 bc[256], u16 gs[m], u16 safe_shift
+//  BM  : u16 first[256] (last-byte shift | 0x8000 if c == P[m-1]), u16 second[256] (the same one byte earlier), u16 bc[256], u16 gs[m], u16 safe_shift
 //  KMP : i16 next[m+1]; u8 dfa[256*256] of P[0..w), w = min(m, kKmpDfaMaxM), 16-byte aligned: state s is row
 //        id(s) = rotl8(s,2) (accept state w: 255), entries are ids, row r XOR-swizzled: delta(r,c) at r*256 + (c ^ r)
 //  SO  : u32 S[256]
