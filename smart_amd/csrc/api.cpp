@@ -201,11 +201,11 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
     // The opposite case: symbols do not repeat (random text over a large alphabet).  Windows then die on
     // their first comparison and a skip kernel only streams; it runs best with FEWER workgroups per CU
     // (kTileWgs in kernels.hip, measured).  Patterns with repeating symbols that still run on a tile
-    // kernel (tune(0,1), KR) keep the lanes busy verifying: more workgroups hide that.  Windows must be
-    // long enough for long shifts (m = 8: 61 % with four workgroups per CU against 75 % with eight).
+    // kernel (tune(0,1), KR) keep the lanes busy verifying: more workgroups hide that.  How many exactly
+    // depends on m and the kernel: tile_wgs() in kernels.hip.
     // (An earlier form — >= 80 % of the first min(m,64) symbols distinct — missed rand128 at m = 64,
     // 50 distinct symbols expected: HOR 80 %, BM 76 %, BNDM 71 % there against 84-87 % at m = 32 and 128.)
-    *sparse = m >= 16 && !repeats;
+    *sparse = m >= 8 && !repeats;
     *halo = std::min<uint32_t>(m - 1, sg::kHaloMax);
     switch (algo) {
         case SMARTGPU_TUNEDBM:  // tunedbm.c:38-40: the same table with a zero for P[m-1] — the flag bit below

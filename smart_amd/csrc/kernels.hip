@@ -157,6 +157,24 @@ __device__ __forceinline__ uint32_t wave_verify(bool has, const uint8_t* tptr,
     return mine;
 }
 
+// Flat tiles are stored dword-swizzled: byte i of the tile region sits at i ^ ((i >> 5) & 0x3C), i.e. the
+// dword index inside its 64-byte block is XORed with bits 7..10 of i.  A lane owns 64 consecutive bytes,
+// so at the same offset x the 64 lanes' addresses differ by multiples of 64 bytes = 16 dwords: unswizzled
+// that is TWO banks for the whole wave — and on random text over a large alphabet the lanes do move in
+// lockstep (nearly every shift is m).  Swizzled, 32 consecutive lanes cover the 32 banks.
+static __device__ __forceinline__ uint32_t tile_at(uint32_t i) { return i ^ ((i >> 5) & 0x3Cu); }
+
+// park one 16-byte chunk (unswizzled byte index i0, a multiple of 16) of the tile region
+static __device__ __forceinline__ void tile_park(uint8_t* txt, uint32_t i0, const uint4& v)
+{
+    uint32_t* blk = reinterpret_cast<uint32_t*>(txt + (i0 & ~63u));
+    const uint32_t d = (i0 >> 2) & 15u, s = (i0 >> 7) & 15u;
+    blk[(d + 0) ^ s] = v.x;
+    blk[(d + 1) ^ s] = v.y;
+    blk[(d + 2) ^ s] = v.z;
+    blk[(d + 3) ^ s] = v.w;
+}
+
 // ---------------------------------------------------------------------------
 // Horspool  (reference: src/algos/hor.c:26-51)
 // LDS: u16 tab[256] | pattern tail P[m-1-H..m-1] | text [tile0-H16, tile0+TB)
@@ -214,13 +232,13 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
         const uint64_t tile0 = t * TB;
         __syncthreads();  // previous tile fully consumed (and tables visible)
         {
-            uint8_t* dst = txt + H16 + threadIdx.x * 16u;
-            *reinterpret_cast<uint4*>(dst) = p0;
-            *reinterpret_cast<uint4*>(dst + THREADS * 16) = p1;
-            *reinterpret_cast<uint4*>(dst + THREADS * 32) = p2;
-            *reinterpret_cast<uint4*>(dst + THREADS * 48) = p3;
-            if (halo_lane) *reinterpret_cast<uint4*>(txt + threadIdx.x * 16u) = ph;
-            if (VAR == 2 && threadIdx.x == 0) *reinterpret_cast<uint4*>(txt + H16 + TB) = pf;
+            const uint32_t i0 = H16 + threadIdx.x * 16u;
+            tile_park(txt, i0, p0);
+            tile_park(txt, i0 + THREADS * 16, p1);
+            tile_park(txt, i0 + THREADS * 32, p2);
+            tile_park(txt, i0 + THREADS * 48, p3);
+            if (halo_lane) tile_park(txt, threadIdx.x * 16u, ph);
+            if (VAR == 2 && threadIdx.x == 0) tile_park(txt, H16 + TB, pf);
         }
         __syncthreads();
         if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
@@ -237,22 +255,22 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_fi
                 if (VAR >= 3) {
                     uint32_t h = 0;
 #pragma unroll
-                    for (int q = VAR - 1; q >= 0; --q) h = (h << 1) + txt[e - q];
+                    for (int q = VAR - 1; q >= 0; --q) h = (h << 1) + txt[tile_at(e - q)];
                     ent = tab[h & 0xFFu];
                 } else {
-                    ent = VAR == 2 ? tab[txt[e + 1]] : tab[txt[e]];
+                    ent = VAR == 2 ? tab[txt[tile_at(e + 1)]] : tab[txt[tile_at(e)]];
                     // (bm_scan's trick — reading the byte before the last along with it, so that a window
                     // that dies there costs no walk — measured here: m >= 32 unchanged, m = 8..16 74-84 % ->
                     // 48-74 %: this loop is LDS-bound at small m and the flat tile's byte reads conflict.)
                 }
-                if (VAR == 2 ? txt[e] == plast : (ent & 0x8000u) != 0) {
+                if (VAR == 2 ? txt[tile_at(e)] == plast : (ent & 0x8000u) != 0) {
                     uint32_t k = VAR >= 3 ? 0 : 1;  // bytes matched so far, right to left (a hash proves nothing)
                     if (VAR == 1 && !LONG) {  // raita.c:56-57: middle byte, first byte
                         const uint32_t mid = m / 2;
-                        if (txt[e - (m - 1) + mid] != ptail[H - (m - 1 - mid)] || txt[e - (m - 1)] != ptail[H - (m - 1)])
+                        if (txt[tile_at(e - (m - 1) + mid)] != ptail[H - (m - 1 - mid)] || txt[tile_at(e - (m - 1))] != ptail[H - (m - 1)])
                             k = H + 2;  // not a match
                     }
-                    while (k <= H && ptail[H - k] == txt[e - k]) ++k;
+                    while (k <= H && ptail[H - k] == txt[tile_at(e - k)]) ++k;
                     bool ok = k == H + 1;
                     if (LONG && ok) {  // the rest of the window is not in LDS
                         const uint8_t* rest = a.text + tile0 + (e - H16) - (m - 1);
@@ -523,13 +541,13 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
     for (; t < t_end; t += gridDim.x) {
         const uint64_t tile0 = t * TB;
         __syncthreads();
-        {
-            uint8_t* dst = txt + H16 + threadIdx.x * 16u;
-            *reinterpret_cast<uint4*>(dst) = p0;
-            *reinterpret_cast<uint4*>(dst + THREADS * 16) = p1;
-            *reinterpret_cast<uint4*>(dst + THREADS * 32) = p2;
-            *reinterpret_cast<uint4*>(dst + THREADS * 48) = p3;
-            if (halo_lane) *reinterpret_cast<uint4*>(txt + threadIdx.x * 16u) = ph;
+        {   // dword-swizzled like hor_scan's tile (tile_at)
+            const uint32_t i0 = H16 + threadIdx.x * 16u;
+            tile_park(txt, i0, p0);
+            tile_park(txt, i0 + THREADS * 16, p1);
+            tile_park(txt, i0 + THREADS * 32, p2);
+            tile_park(txt, i0 + THREADS * 48, p3);
+            if (halo_lane) tile_park(txt, threadIdx.x * 16u, ph);
         }
         __syncthreads();
         if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
@@ -543,8 +561,8 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
             const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
             while (e < ehi) {
                 // right-to-left comparison (bm.c:83); k = bytes matched
-                uint32_t c = txt[e];
-                const uint32_t c1 = txt[e - 1];  // m = 1 at the tile's first byte: a byte of ptail's padding, unused
+                uint32_t c = txt[tile_at(e)];
+                const uint32_t c1 = txt[tile_at(e - 1)];  // m = 1 at the tile's first byte: a byte of ptail's padding, unused
                 const uint32_t ent = first[c];
                 if (!(ent & 0x8000u)) {  // mismatch on the last byte: bm.c:89 with i = m-1
                     e += ent;
@@ -558,7 +576,7 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
                 uint32_t k = 2;
                 bool mismatch = false;
                 while (k <= H) {
-                    c = txt[e - k];
+                    c = txt[tile_at(e - k)];
                     if (c != ptail[H - k]) { mismatch = true; break; }
                     ++k;
                 }
@@ -644,13 +662,13 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
     for (; t < t_end; t += gridDim.x) {
         const uint64_t tile0 = t * TB;
         __syncthreads();
-        {
-            uint8_t* dst = txt + H16 + threadIdx.x * 16u;
-            *reinterpret_cast<uint4*>(dst) = p0;
-            *reinterpret_cast<uint4*>(dst + THREADS * 16) = p1;
-            *reinterpret_cast<uint4*>(dst + THREADS * 32) = p2;
-            *reinterpret_cast<uint4*>(dst + THREADS * 48) = p3;
-            if (halo_lane) *reinterpret_cast<uint4*>(txt + threadIdx.x * 16u) = ph;
+        {   // dword-swizzled like hor_scan's tile (tile_at)
+            const uint32_t i0 = H16 + threadIdx.x * 16u;
+            tile_park(txt, i0, p0);
+            tile_park(txt, i0 + THREADS * 16, p1);
+            tile_park(txt, i0 + THREADS * 32, p2);
+            tile_park(txt, i0 + THREADS * 48, p3);
+            if (halo_lane) tile_park(txt, threadIdx.x * 16u, ph);
         }
         __syncthreads();
         if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
@@ -665,7 +683,7 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
             while (e < ehi) {
                 // bndm.c:49-58 with the first step peeled: D = ~0 & B[c], and B[c] == 0 (c does
                 // not occur in the prefix) moves the window by w after one text and one table read
-                uint32_t D = B[txt[e]];
+                uint32_t D = B[txt[tile_at(e)]];
                 if (D == 0) {
                     // sbndm.c:60-63 reads a second byte before it tests D and so moves by w-1
                     // here; its long-pattern form skips by w like BNDM (sbndm.c:133)
@@ -675,7 +693,7 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
                 if (SIMPLE) {
                     uint32_t k = 1;
                     for (;;) {  // sbndm.c:61-65
-                        D = (D << 1) & B[txt[e - k]];
+                        D = (D << 1) & B[txt[tile_at(e - k)]];
                         if (k == w - 1 || D == 0) break;
                         ++k;
                     }
@@ -704,7 +722,7 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
                 for (;;) {
                     if ((int32_t)D < 0 && k < w) last = w - k;
                     if (k == w) break;  // the whole window is read and D != 0: an occurrence
-                    D = (D << 1) & B[txt[e - k]];
+                    D = (D << 1) & B[txt[tile_at(e - k)]];
                     if (D == 0) break;
                     ++k;
                 }
@@ -2090,7 +2108,14 @@ uint32_t r16(uint32_t x) { return (x + 15u) & ~15u; }
 // 8 TB/s with 4, 78-82 % with 8, 75 % with 6, 82 % with 16 (two rounds) — profiles/r01/
 // o_wgs_per_cu.log; BM and BNDM follow the same curve.  Where lanes spend their time verifying
 // (English text: HOR m=64 47 % with 8, 40 % with 4) the extra waves pay: EIGHT.
-static int tile_wgs(const ScanArgs& a) { return a.sparse ? 4 : 8; }
+// Short windows (8 <= m < 16) of such patterns: FIVE (HOR m = 8..13: 75-83 % with 5, 74-83 % with 6, 68-83 %
+// with 4, 71-74 % with 8).  bm_scan, with its larger tables: THREE for m >= 16 (83-84 % against 79-82 % with 4).
+static int tile_wgs(const ScanArgs& a, bool bm = false)
+{
+    if (!a.sparse) return 8;
+    if (a.m < 16) return bm ? 4 : 5;  // bm_scan m = 12, 14: 78-80 % with 4, 75 % with 5
+    return bm ? 3 : 4;
+}
 
 template <typename K>
 hipError_t launch_tiled(K kernel, const ScanArgs& a, TileRange tr, int threads, size_t lds,
@@ -2346,7 +2371,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBpThreads * kBpL);
                 return launch_tiled(hor_scan_bp<false>, a, tr, kBpThreads, lds, 5, num_cus, stream);
             }
-            const size_t lds = 512 + r16(H + 1) + r16(H) + (size_t)kHorT * kHorL;
+            const size_t lds = 512 + r16(H + 1) + ((r16(H) + (size_t)kHorT * kHorL + 16 + 63) & ~(size_t)63);  // whole 64-byte blocks: tile_at() permutes inside them
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
             if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 0>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);
             return launch_tiled(hor_scan<kHorT, kHorL, false, 0>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);
@@ -2368,7 +2393,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 b.fp_off = kTableOff + 768;
                 return launch_packed<SMARTGPU_HOR>(b, num_cus, stream);
             }
-            const size_t lds = 512 + r16(H + 1) + r16(H) + (size_t)kHorT * kHorL + 16;
+            const size_t lds = 512 + r16(H + 1) + ((r16(H) + (size_t)kHorT * kHorL + 16 + 63) & ~(size_t)63);  // whole 64-byte blocks: tile_at() permutes inside them
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
 #define SG_HOR_VAR(V_)                                                                                     \
     do {                                                                                                  \
@@ -2390,9 +2415,9 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 return launch_packed<SMARTGPU_BM>(b, num_cus, stream);
             }
             const uint32_t H = a.halo;
-            const size_t lds = 1536 + r16(2 * (m + 1)) + r16(H + 1) + r16(H) + (size_t)kBmT * kBmL;
+            const size_t lds = 1536 + r16(2 * (m + 1)) + r16(H + 1) + ((r16(H) + (size_t)kBmT * kBmL + 63) & ~(size_t)63);  // whole 64-byte blocks (tile_at)
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmT * kBmL);
-            const int wgs = tile_wgs(a);
+            const int wgs = tile_wgs(a, true);
             if (m - 1 > H) return launch_tiled(bm_scan<kBmT, kBmL, true>, a, tr, kBmT, lds, wgs, num_cus, stream);
             return launch_tiled(bm_scan<kBmT, kBmL, false>, a, tr, kBmT, lds, wgs, num_cus, stream);
         }
@@ -2425,7 +2450,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 return launch_packed<SMARTGPU_BNDM>(b, num_cus, stream);
             }
             const uint32_t w = m < 32 ? m : 32;
-            const size_t lds = 1024 + 32 + (size_t)kBndmT * kBndmL;
+            const size_t lds = 1024 + ((32 + (size_t)kBndmT * kBndmL + 63) & ~(size_t)63);  // whole 64-byte blocks (tile_at)
             const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
             if (algo == SMARTGPU_SBNDM) {
                 if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
