@@ -1878,6 +1878,18 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_
     // dword ^ f0, 2.25 instead of 3.25 VALU ops per alignment), two steps of loads in flight in
     // registers, and capping the resident workgroups through an LDS allocation — all within noise of
     // 76-80 %; the VALU is 63 % busy, the waves wait on memory half of their time (PMC).
+    // Session t, all measured and dropped:
+    //  * the same rows over hor_scan's data path (16 KB tiles staged in LDS with non-temporal loads, every
+    //    byte fetched once, four workgroups per CU): rand128 68-82 % (here 70-81 %), English 43-60 % (47-74 %),
+    //    rand4 52-57 % (63-66 %) — with candidates in most rows the few resident waves cannot hide the deeper
+    //    fingerprint dwords and the verification;
+    //  * natural language: a pattern whose first dword is frequent ("And ", "of t") runs two or three dword
+    //    stages in most rows (42-55 % against 65-74 % for other English patterns).  Comparing the rarest
+    //    dword first — picked from the pattern's own symbol counts, or from byte counts of the text — moved
+    //    single patterns both ways (byte counts know nothing of "\nAnd"); comparing the XOR of the four
+    //    dwords first (the funnel shift is linear over XOR: +1 op per alignment) lifted the worst patterns
+    //    to 56-72 % but cost the median English pattern 2-4 points and rand32 8; choosing the dword at run
+    //    time inside this loop cost EVERY pattern 20 % (rand128 80 % -> 62 %).
     constexpr bool NTA = POLICY != 1, NTB = false;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 128 bytes: flush_hits
     const uint32_t* fpw = reinterpret_cast<const uint32_t*>(a.blob + a.fp_off);
