@@ -263,9 +263,11 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
                 blob.resize((blob.size() + 15) & ~size_t(15), 0);
                 const std::vector<uint8_t> dfa = sg::kmp_dfa(P, w);
                 // State s becomes row id(s) = rotl8(s, 2), the accept state w row 255 (no other state maps
-                // there: rotl8(s, 2) = 255 only for s = 255); row r is stored XOR-swizzled by r.  Why:
+                // there: rotl8(s, 2) = 255 only for s = 255) — or row 4w while the ids 4s do not wrap (w < 64),
+                // so that short patterns keep a short table; row r is stored XOR-swizzled by r.  Why:
                 // kmp_runs in kernels.hip (LDS bank spread on small alphabets, accept = largest id).
-                auto id = [w](uint32_t st) { return st == w ? 255u : ((st << 2) | (st >> 6)) & 255u; };
+                const uint32_t acc = w < 64 ? 4 * w : 255u;  // the largest id in use
+                auto id = [w, acc](uint32_t st) { return st == w ? acc : ((st << 2) | (st >> 6)) & 255u; };
                 std::vector<uint8_t> sw(256 * 256, 0);
                 for (uint32_t st = 0; st <= w; ++st) {
                     const uint32_t r = id(st);

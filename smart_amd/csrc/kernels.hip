@@ -1290,12 +1290,12 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t w = PREFIX ? kKmpDfaMaxM : m;  // length the automaton recognises
     // States are renumbered on the host (api.cpp build_blob): state s is row rotl8(s, 2), the accept state
-    // row 255 — the largest id, which the running maximum needs.  A row's entries are XOR-swizzled by the
+    // row 255 (row 4w when there are fewer than 64 states) — the largest id, which the running maximum needs.  A row's entries are XOR-swizzled by the
     // row id, so a lookup's LDS bank is ((c ^ id) >> 2) & 31: with ids 0, 4, 8, ... the states a lane is
     // usually in (the low ones) sit on different banks even when c is one of two values.  Numbered 0..w
     // they shared banks 0 and 1 there (rand2: 49-53 % of 8 TB/s, rand4: 55-60 %).
-    constexpr uint32_t acc = 255;
-    constexpr uint32_t table_bytes = 256 * 256;
+    const uint32_t acc = w < 64 ? 4 * w : 255u;  // ids 0, 4, .., 4(w-1) do not wrap below 64 states: the table ends there
+    const uint32_t table_bytes = (acc + 1) * 256;
     const RunIo io = run_io(smem + table_bytes + wave * kLineSlab, lane, run_len);
     {
         const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
@@ -2265,7 +2265,7 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
         return hipGetLastError();
     }
     // one 1024-thread workgroup per CU shares the table (<= 64 KB) next to 16 x 4 KB of slabs
-    const size_t lds = 256 * 256 + kRunWaves * (size_t)kLineSlab;  // all 256 rows: state ids are spread over them (kmp_runs)
+    const size_t lds = (size_t)(w < 64 ? 4 * w + 1 : 256) * 256 + kRunWaves * (size_t)kLineSlab;  // rows up to the accept id (kmp_runs)
     // runs of 2-4 KiB: at least 8x the w-1 bytes a run re-scans, at most 8 KiB (the loader's
     // over-read past the last run stays inside the text's back pad)
     uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
