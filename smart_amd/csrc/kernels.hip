@@ -431,10 +431,19 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
                 // the same because every equal hash is confirmed byte by byte (m < 8: the rolling form
                 // with the outgoing byte below).  Equal hashes are rare: a running minimum of the masked
                 // difference says whether a group of 16 has one, and only then are its ends looked at.
+                // Four bytes at a time: after the dword d = b0 b1 b2 b3 the hash is 16h + 8b0 + 4b1 + 2b2 + b3, and
+                // the hashes at the three ends in between are (h << s) + the dot product of d with (2^(s-1), ..,
+                // 1, 0, ..): one v_dot4_u32_u8 and one v_lshl_add each, all four from the same h (no chain
+                // through the dword).  The hash the lane starts with — the 32 bytes before its first end — is
+                // the lower half of the PREVIOUS lane's column: 8 dword reads, 8 dot products.
                 const uint32_t kr_mask = kr_w == 32 ? 0xFFFFFFFFu : (1u << kr_w) - 1u;
-                uint32_t h = 0;
-                for (uint32_t k = 1; k <= 32; ++k) h += (uint32_t)txt[bp_addr(e - k)] << (k - 1);  // window ending at e-1
                 const uint8_t* col = txt + (kBpHaloCols + tid) * 4u;
+                uint32_t h = 0;
+#pragma unroll
+                for (int r = 8; r < 16; ++r) {
+                    const uint32_t d = *reinterpret_cast<const uint32_t*>(col - 4 + r * kBpRowBytes);
+                    h = __builtin_amdgcn_udot4(d, 0x01020408u, h << 4, false);
+                }
 #pragma unroll 1
                 for (uint32_t g = 0; g < 4; ++g) {
                     const uint32_t h0 = h;
@@ -442,16 +451,24 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
 #pragma unroll
                     for (int r = 0; r < 4; ++r) d[r] = *reinterpret_cast<const uint32_t*>(col + (4 * g + r) * kBpRowBytes);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        h = (h << 1) + ((d[i >> 2] >> (8 * (i & 3))) & 0xFFu);  // kr.c:26,48
-                        near = min(near, (h ^ kr_hp) & kr_mask);
+                    for (int r = 0; r < 4; ++r) {
+                        const uint32_t h1 = (h << 1) + __builtin_amdgcn_udot4(d[r], 0x00000001u, 0u, false);  // kr.c:26,48
+                        const uint32_t h2 = (h << 2) + __builtin_amdgcn_udot4(d[r], 0x00000102u, 0u, false);
+                        const uint32_t h3 = (h << 3) + __builtin_amdgcn_udot4(d[r], 0x00010204u, 0u, false);
+                        h = (h << 4) + __builtin_amdgcn_udot4(d[r], 0x01020408u, 0u, false);
+                        near = min(near, min((h1 ^ kr_hp) & kr_mask, (h2 ^ kr_hp) & kr_mask));
+                        near = min(near, min((h3 ^ kr_hp) & kr_mask, (h ^ kr_hp) & kr_mask));
                     }
-                    if (near == 0) {  // kr.c:47: some end in this group has the pattern's hash: confirm
-                        uint32_t hh = h0;
-                        for (uint32_t i = 0; i < 16; ++i) {
-                            const uint32_t ee = e + 16 * g + i;
-                            hh = (hh << 1) + txt[bp_addr(ee)];
-                            if (((hh ^ kr_hp) & kr_mask) != 0) continue;
+                    if (near == 0) {  // kr.c:47: some end in this group has the pattern's hash: which, from the registers
+                        uint32_t hh = h0, hm = 0;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            hh = (hh << 1) + ((d[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+                            hm |= ((hh ^ kr_hp) & kr_mask) == 0 ? (1u << i) : 0u;
+                        }
+                        while (hm) {  // ... and confirm those byte by byte
+                            const uint32_t ee = e + 16 * g + (uint32_t)__builtin_ctz(hm);
+                            hm &= hm - 1;
                             uint32_t k = 0;
                             while (k <= H && ptail[H - k] == txt[bp_addr(ee - k)]) ++k;
                             bool ok = k == H + 1;
@@ -2392,7 +2409,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             const uint32_t H = a.halo;
             const size_t lds = kBpTabBytes + r16(H + 1) + kBpTextBytes;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBpThreads * kBpL);
-            return launch_tiled(hor_scan_bp<true>, a, tr, kBpThreads, lds, 5, num_cus, stream);
+            return launch_tiled(hor_scan_bp<true>, a, tr, kBpThreads, lds, 6, num_cus, stream);
         }
         case SMARTGPU_HASH3:
         case SMARTGPU_HASH5:
