@@ -318,6 +318,7 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             uint32_t hp = 0;
             for (uint32_t i = 0; i < m; ++i) hp = (hp << 1) + P[i];
             append(&hp, 4);
+            append_fingerprint();  // packed regime (m < 16), at kTableOff + 4
             *halo = std::min<uint32_t>(m - 1, 32);  // bytes confirmed in LDS (and the hash's reach) behind a window end
             break;
         }

@@ -2168,9 +2168,9 @@ static constexpr uint32_t packed_max_m(int algo)
     return (algo == SMARTGPU_HOR || algo == SMARTGPU_TUNEDBM || algo == SMARTGPU_RAITA) ? 7u
          : algo == SMARTGPU_BM ? 8u : algo == SMARTGPU_BNDM ? 11u
          : algo == SMARTGPU_QS ? 14u     // three LDS reads per window (text byte, next byte, table): later crossover
-         : algo == SMARTGPU_HASH3 ? 32u  // q text reads + hash + table per window, shifts of at most m-q+1:
-         : algo == SMARTGPU_HASH5 ? 64u  //   the tiles pass the packed matcher's 78 % only here
-         : algo == SMARTGPU_HASH8 ? 28u  //   (profiles/r01/n_sweep_hash_mid.log)
+         : algo == SMARTGPU_HASH3 ? 24u  // q text reads + hash + table per window, shifts of at most m-q+1: the
+         : algo == SMARTGPU_HASH5 ? 32u  //   tiles pass the packed matcher's 78-81 % only here (with four workgroups
+         : algo == SMARTGPU_HASH8 ? 80u  //   per CU; HASH8 own/packed: m=32 63/79, 64: 78/81, 96: 82/81 — session u)
          : 0u;
 }
 
@@ -2199,7 +2199,7 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_m
         case SMARTGPU_RAITA:
         case SMARTGPU_QS: return (pk || hor_regime(m, algo) == 3) ? "packed_scan" : "hor_scan";
         case SMARTGPU_SA: return "so_runs";
-        case SMARTGPU_KR: return "hor_scan_bp";
+        case SMARTGPU_KR: return (m < 16 && g_tune[0] != 1) ? "packed_scan" : "hor_scan_bp";
         case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
         case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : "kmp_runs";
         case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : "so_runs";
@@ -2406,6 +2406,14 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             return launch_tiled(hor_scan<kHorT, kHorL, false, 0>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);
         }
         case SMARTGPU_KR: {  // rolling hash on the bank-private tiles; a.halo = min(m-1, 32) (api.cpp)
+            if (m < 16 && g_tune[0] != 1) {
+                // Short patterns, like the skip algorithms': the packed matcher (72-77 %).  Only the low m bits
+                // of the rolled hash can be compared, so one window end in 2^m is confirmed (m = 8: 32 %,
+                // m = 12: 50 % of 8 TB/s), and below 8 the rolling form needs the outgoing byte (15 %).
+                ScanArgs b = a;
+                b.fp_off = kTableOff + 4;  // after the pattern's hash
+                return launch_packed<SMARTGPU_HOR>(b, num_cus, stream);
+            }
             const uint32_t H = a.halo;
             const size_t lds = kBpTabBytes + r16(H + 1) + kBpTextBytes;
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBpThreads * kBpL);

@@ -85,7 +85,7 @@ def test_horspool_variants(oracle, variant):
 
 def test_skip_loops_forced_for_short_patterns(oracle):
     """m <= 16 normally goes to the packed matcher; force the LDS-tile skip loops of
-    BM and BNDM so that they stay covered for short patterns too."""
+    BM and BNDM (and Karp-Rabin's own kernel) so that they stay covered for short patterns too."""
     from smart_amd import engine
     engine.tune(0, 1)
     try:
@@ -94,9 +94,9 @@ def test_skip_loops_forced_for_short_patterns(oracle):
                 continue
             P, T = fuzz_case(oracle, r)
             text = Text.upload(T)
-            got = gpu_counts(P, text, algos=("bm", "bndm"))
+            got = gpu_counts(P, text, algos=("bm", "bndm", "kr"))  # kr: its own kernel (m < 8: the subtracting rolling hash)
             text.free()
-            assert got["bm"] == r["count"] and got["bndm"] == r["count"], (r, got)
+            assert got["bm"] == r["count"] and got["bndm"] == r["count"] and got["kr"] == r["count"], (r, got)
     finally:
         engine.tune(0, 0)
 
