@@ -2166,7 +2166,7 @@ int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static constexpr uint32_t packed_max_m(int algo)
 {
     return (algo == SMARTGPU_HOR || algo == SMARTGPU_TUNEDBM || algo == SMARTGPU_RAITA) ? 7u
-         : algo == SMARTGPU_BM ? 8u : algo == SMARTGPU_BNDM ? 11u
+         : algo == SMARTGPU_BM ? 7u : algo == SMARTGPU_BNDM ? 10u  // re-measured with five workgroups per CU below 16 bytes (session u)
          : algo == SMARTGPU_QS ? 14u     // three LDS reads per window (text byte, next byte, table): later crossover
          : algo == SMARTGPU_HASH3 ? 24u  // q text reads + hash + table per window, shifts of at most m-q+1: the
          : algo == SMARTGPU_HASH5 ? 32u  //   tiles pass the packed matcher's 78-81 % only here (with four workgroups
