@@ -151,6 +151,10 @@ int smartgpu_plan_launch(smartgpu_plan *p, const smartgpu_text *text, uint64_t o
 int smartgpu_plan_result(smartgpu_plan *p, int slot, uint64_t *count, double *kernel_ms);
 /* Name of the dominant kernel the plan launches (as rocprofv3 reports it). */
 const char *smartgpu_plan_kernel_name(const smartgpu_plan *p);
+/* The same for (algo, P, m) without a device: which kernel a plan of this pattern would launch under the
+ * current smartgpu_tune() settings — the host-side choice (DESIGN.md §4 "The plan reads the pattern").  NULL
+ * if algo or m is out of range. */
+const char *smartgpu_kernel_for(int algo, const uint8_t *P, uint32_t m);
 /* Device address of the plan's uint64 result slots (for an RCCL reduce issued
  * by the caller on the same device). */
 void *smartgpu_plan_result_device_ptr(smartgpu_plan *p);

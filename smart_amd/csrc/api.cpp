@@ -618,6 +618,17 @@ const char* smartgpu_plan_kernel_name(const smartgpu_plan* p)
     return p ? sg::scan_kernel_name(p->algo, p->m, p->prefer_packed != 0, p->so_off != 0) : nullptr;
 }
 
+const char* smartgpu_kernel_for(int algo, const uint8_t* P, uint32_t m)
+{
+    if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS || !P || m < 1 || m > SMARTGPU_XSIZE || m < min_pattern(algo)) {
+        set_error("kernel_for: algorithm %d / pattern length %u not applicable", algo, m);
+        return nullptr;
+    }
+    uint32_t halo = 0, prefer_packed = 0, sparse = 0, so_off = 0;
+    (void)build_blob(algo, P, m, &halo, &prefer_packed, &sparse, &so_off);
+    return sg::scan_kernel_name(algo, m, prefer_packed != 0, so_off != 0);
+}
+
 void* smartgpu_plan_result_device_ptr(smartgpu_plan* p) { return p ? p->slot_ptr(0) : nullptr; }
 
 int smartgpu_plan_reset(smartgpu_plan* p)

@@ -61,6 +61,7 @@ def lib():
         "smartgpu_plan_launch": (i32, [vp, vp, u64, u64, i32, i32]),
         "smartgpu_plan_result": (i32, [vp, i32, C.POINTER(u64), C.POINTER(C.c_double)]),
         "smartgpu_plan_kernel_name": (C.c_char_p, [vp]),
+        "smartgpu_kernel_for": (C.c_char_p, [i32, vp, u32]),
         "smartgpu_plan_result_device_ptr": (vp, [vp]),
         "smartgpu_build_table": (i32, [i32, vp, u32, vp, u32]),
         "smartgpu_plan_reset": (i32, [vp]),
@@ -336,6 +337,15 @@ def probe_read_gbs(text, reps=20):
 def tune(key, value):
     if lib().smartgpu_tune(key, value) != 0:
         raise _err("tune")
+
+
+def kernel_for(algo, P):
+    """Kernel a plan of (algo, P) would launch under the current tune settings; no device needed."""
+    P = _u8(P)
+    name = lib().smartgpu_kernel_for(algo_id(algo), P.ctypes.data, len(P))
+    if name is None:
+        raise _err("kernel_for")
+    return name.decode()
 
 
 def build_table(which, P):

@@ -161,3 +161,45 @@ int main() {
                            "-I", os.path.join(ROOT, "smart_amd", "csrc"), str(drv), src, "-o", str(exe)])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
+
+def test_kernel_choice_follows_the_pattern(oracle):
+    """The plan picks the kernel from the pattern's own symbols (api.cpp build_blob, DESIGN.md §4);
+    smartgpu_kernel_for answers without a device."""
+    from smart_amd import engine
+    kf = smart_amd.kernel_for
+    rnd = oracle.gen_text(123, 128, 0, 5000)       # rand128: symbols do not repeat
+    eng = np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "english_excerpt.txt"), "rb").read(5000), dtype=np.uint8)
+    two = oracle.gen_text(9, 2, 0, 5000)
+    four = oracle.gen_text(9, 4, 0, 5000)
+    # own LDS-tile skip kernels on random text over a large alphabet
+    for m in (32, 64, 256, 4096):
+        assert kf("hor", rnd[:m]) == "hor_scan" and kf("bm", rnd[:m]) == "bm_scan" and kf("bndm", rnd[:m]) == "bndm_scan"
+        assert kf("bndml", rnd[:m]) == ("bndm_scan" if m <= 32 else "bndml_scan")
+        assert kf("kr", rnd[:m]) == "hor_scan_bp"
+    # short patterns: the packed matcher (crossovers per algorithm)
+    assert kf("hor", rnd[:7]) == "packed_scan" and kf("hor", rnd[100:108]) in ("hor_scan", "packed_scan")
+    assert kf("bm", rnd[:7]) == "packed_scan" and kf("bndm", rnd[:10]) == "packed_scan" and kf("kr", rnd[:15]) == "packed_scan"
+    # natural language, DNA-like alphabets: symbols repeat -> packed matcher at any m
+    for m in (16, 64, 1024):
+        for a in ("hor", "bm", "bndm", "qs", "raita", "hash3", "sbndm", "bndml", "tunedbm"):
+            assert kf(a, eng[200:200 + m]) == "packed_scan", (a, m)
+            assert kf(a, four[:m]) in ("packed_scan", "so_runs"), (a, m)  # so_runs when its first four symbols are the frequent ones
+    # two symbols, 16+ bytes: the bit-parallel runs kernel, whatever the algorithm (KMP and KR keep their own)
+    for m in (16, 33, 300):
+        for a in engine.ALGOS:
+            want = {"kmp": "kmp_runs", "kr": "hor_scan_bp"}.get(a, "so_runs")
+            assert kf(a, two[:m]) == want, (a, m)
+    assert kf("hor", two[:12]) == "packed_scan"
+    # the serial automata never move
+    for P in (rnd[:32], eng[:32], four[:32]):
+        assert kf("kmp", P) == "kmp_runs" and kf("so", P) == "so_runs" and kf("sa", P) == "so_runs"
+    assert kf("epsm", rnd[:32]) == "packed_scan" and kf("epsm", eng[:32]) == "packed_scan"
+    # tune(0,1): every algorithm on its own kernel
+    engine.tune(0, 1)
+    try:
+        assert kf("bm", eng[200:264]) == "bm_scan" and kf("hor", two[:64]) == "hor_scan" and kf("kr", rnd[:8]) == "hor_scan_bp"
+    finally:
+        engine.tune(0, 0)
+    with pytest.raises(smart_amd.SmartGpuError):
+        kf("hash8", rnd[:7])
