@@ -1241,6 +1241,10 @@ __device__ __forceinline__ void kmp_dfa_chunk_max(const uint4& v, uint32_t& st, 
 // byte.  So the two halves of a line are requested back to back (load i: bytes 0..63 of runs
 // 16i + lane/4, load 4+i: bytes 64..127 of the same runs), held in registers, and the slab
 // stays [64 runs][64 B]: 4 KB per wave, 16 waves per CU next to any table.
+// Tried and dropped (session u): load i fetching the whole 128-byte lines of 8 runs (eight lanes per line, like a
+// contiguous read; parking then stores with half the lanes per half) instead of 64-byte halves of 16 runs: SO
+// 65 % as before, KMP 64-68 % -> 55-60 %; 8 or 12 waves per CU instead of 16: 40-54 %; runs of 256..4096 bytes:
+// within 3 points of each other.
 // Tried and dropped (measured on rand128, 1 GiB): two runs per lane with interleaved lookups
 // (57-59 % against 65-67 %), groups handed out by a device-wide atomic counter (same-address
 // atomics serialise at ~16 ns and, returning through vmcnt, stall every wave's first fetch:
