@@ -305,6 +305,11 @@ def test_two_symbol_patterns_count_on_shift_or_runs_and_on_their_own_kernels(ora
                     pl.free()
                 got = gpu_counts(P, text)
                 assert all(v == want for v in got.values()), (sigma, m, got, want)
+                if m in (17, 100, 4096):  # a shard-style sub-range through the rerouted plans
+                    off, nn = 123_457, 700_001
+                    sub = oracle.search("hor", P, T[off:off + nn])
+                    for a in ("hor", "bm", "bndm", "epsm", "qs", "bndml"):
+                        assert smart_amd.search(a, P, text, off=off, n=nn)[0] == sub, (a, sigma, m)
                 engine.tune(0, 1)
                 try:
                     pl = Plan("bm", P)
