@@ -283,8 +283,8 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             break;
         }
         case SMARTGPU_BNDML:
-            if (m > 32) {  // bndml.c:91-93: bit i of word i/32 of B[c] <=> P[w-1-i] == c, over w = min(m, 256) bytes
-                const uint32_t w = std::min<uint32_t>(m, 256);
+            if (m > 32) {  // bndml.c:91-93: bit i of word i/32 of B[c] <=> P[w-1-i] == c, over w = min(m, kBndmlWindow) bytes
+                const uint32_t w = std::min<uint32_t>(m, sg::kBndmlWindow);
                 const uint32_t W = w <= 64 ? 2 : w <= 128 ? 4 : 8;
                 std::vector<uint32_t> B(256 * W, 0u);
                 for (uint32_t i = 0; i < w; ++i) B[P[w - 1 - i] * W + i / 32] |= 1u << (i % 32);

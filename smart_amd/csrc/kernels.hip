@@ -770,19 +770,22 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
 // BNDM with multi-word bit vectors  (src/algos/bndml.c:82-132, search_large; m <= 32 is plain BNDM
 // and runs on bndm_scan).  The whole window lives in W = 2, 4 or 8 words held in registers, the
 // shift carries from word to word, bit w-1 of D after k bytes says "the last k bytes are a prefix
-// of P" (shift = w - longest such k).  w = min(m, 256): the reference keeps ceil(m/32) words for
-// any m (its table is 128 KB at m = 4096); here a pattern longer than 256 bytes is filtered by its
-// 256-byte prefix and the rest is verified in memory, as the single-word algorithms do with 32.
+// of P" (shift = w - longest such k).  w = min(m, kBndmlWindow = 64), W = 2: the reference keeps
+// ceil(m/32) words for any m (its table is 128 KB at m = 4096); here a longer pattern is filtered by
+// its 64-byte prefix and the rest is verified in memory, as the single-word algorithms do with 32.
+// (The kernel is written for any W; with 256-byte windows, W = 8, the eight-word shift per text byte
+// made it VALU-bound — 72-80 % for m >= 256 against 82-85 % with two words — and a streaming scan has
+// no use for shifts longer than a lane's 64 bytes.)
 // Tiles are indexed by the END of the w-byte window with a 256-byte back halo.
 // LDS: u32 B[256][W] | P[0..w) | text [tile0-256, tile0+TB)
 // ---------------------------------------------------------------------------
-template <int THREADS, int L, int W, bool LONG>  // LONG: m > 256
+template <int THREADS, int L, int W, bool LONG>  // LONG: m > kBndmlWindow
 __global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a, uint64_t tile_first, uint32_t ntiles)
 {
     constexpr int TB = THREADS * L;
     constexpr uint32_t H16 = 256;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t m = a.m, w = m < 256 ? m : 256;
+    const uint32_t m = a.m, w = m < kBndmlWindow ? m : kBndmlWindow;
     uint32_t* B = reinterpret_cast<uint32_t*>(smem);
     uint8_t* pw = smem + 256 * W * 4;  // P[0..w), for the direct comparison below
     uint8_t* txt = pw + 256;
@@ -2464,22 +2467,21 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
         }
         case SMARTGPU_BNDML:
             if (m > 32) {  // multi-word vectors; m <= 32 is plain BNDM (bndml.c:44-75): falls through
-                const uint32_t w = m < 256 ? m : 256;
+                const uint32_t w = m < kBndmlWindow ? m : kBndmlWindow;
                 if (a.prefer_packed && g_tune[0] == 0) {
                     ScanArgs b = a;
-                    b.fp_off = kTableOff + 1024 * (w <= 64 ? 2 : w <= 128 ? 4 : 8) + 4;  // after the masks and the period
+                    b.fp_off = kTableOff + 1024 * 2 + 4;  // after the masks (W = 2) and the period
                     return launch_packed<SMARTGPU_BNDM>(b, num_cus, stream);
                 }
                 const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
 #define SG_BNDML(W_)                                                                                      \
     do {                                                                                                  \
         const size_t lds = 256 * (W_) * 4 + 256 + 256 + (size_t)kBndmT * kBndmL;                          \
-        if (m > 256) return launch_tiled(bndml_scan<kBndmT, kBndmL, W_, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream); \
+        if (m > kBndmlWindow) return launch_tiled(bndml_scan<kBndmT, kBndmL, W_, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream); \
         return launch_tiled(bndml_scan<kBndmT, kBndmL, W_, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);            \
     } while (0)
-                if (w <= 64) SG_BNDML(2);
-                if (w <= 128) SG_BNDML(4);
-                SG_BNDML(8);
+                static_assert(kBndmlWindow <= 64, "wider windows: instantiate bndml_scan with W = 4 (<= 128 bytes) or 8 (<= 256)");
+                SG_BNDML(2);
 #undef SG_BNDML
             }
             [[fallthrough]];

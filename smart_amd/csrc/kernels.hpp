@@ -47,6 +47,7 @@ struct ScanArgs {
 //  BNDM: u32 B[256]
 //  EPSM: u32 fp[4], u32 fpmask[4]   (first min(m,16) pattern bytes as dwords + byte masks)
 constexpr uint32_t kTableOff = kPatternBytes;
+constexpr uint32_t kBndmlWindow = 64;           // bytes of the pattern bndml_scan keeps in its bit vectors (multiple of 32, <= 256)
 
 struct LaunchInfo {
     const char* kernel_name;  // as rocprofv3 prints it
