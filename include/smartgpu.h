@@ -207,7 +207,7 @@ int smartgpu_probe_read_ms(const smartgpu_text *t, int reps, double *ms_per_pass
  *      (failure links followed per byte)
  *   5  run length in bytes of the runs kernels (so_runs, kmp_runs); 0 = default
  *   6  SO: 0 so_runs (bank-private table, line fetch) / 1 so_scan (LDS tiles) / 2 so_runs64
- *      (shared table, 64-byte steps)
+ *      (shared table, 64-byte steps); SA: 3 = its own AND form (default: the complemented, Shift-Or form)
  *   7  packed matcher load policy: 0 A non-temporal + B cached / 1 both cached / 3 one load + shuffle */
 int smartgpu_tune(int key, int value);
 

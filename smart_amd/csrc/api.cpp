@@ -323,6 +323,12 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             break;
         }
         case SMARTGPU_SA: {
+            // sa.c:52 is D = ((D << 1) | 1) & S[c]; with E = ~D that is E = (E << 1) | ~S[c] — Shift-Or's step
+            // on Shift-Or's masks, and "bit w-1 of D set" is "bit w-1 of E clear": the same automaton in
+            // complement.  The kernel runs that form (one VALU op per byte less: there is no shift-and-AND
+            // instruction); the AND form stays selectable (smartgpu_tune(6,3)) on the masks that follow.
+            const std::vector<uint32_t> So = sg::shift_or_masks(P, m);
+            append(So.data(), 1024);
             const std::vector<uint32_t> S = sg::shift_and_masks(P, m);
             append(S.data(), 1024);
             break;

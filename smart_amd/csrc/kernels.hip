@@ -1244,10 +1244,9 @@ __device__ __forceinline__ void kmp_dfa_chunk_max(const uint4& v, uint32_t& st, 
 // byte.  So the two halves of a line are requested back to back (load i: bytes 0..63 of runs
 // 16i + lane/4, load 4+i: bytes 64..127 of the same runs), held in registers, and the slab
 // stays [64 runs][64 B]: 4 KB per wave, 16 waves per CU next to any table.
-// Tried and dropped (session u): load i fetching the whole 128-byte lines of 8 runs (eight lanes per line, like a
-// contiguous read; parking then stores with half the lanes per half) instead of 64-byte halves of 16 runs: SO
-// 65 % as before, KMP 64-68 % -> 55-60 %; 8 or 12 waves per CU instead of 16: 40-54 %; runs of 256..4096 bytes:
-// within 3 points of each other.
+// Tried and dropped (session u): 8 or 12 waves per CU instead of 16: 40-54 %; runs of 256..4096 bytes: within 3
+// points of each other.  (Whole-line loads of 8 runs per instruction were equal-or-worse WITHOUT non-temporal
+// loads; with them they are so_runs' loader now — LineIo below.)
 // Tried and dropped (measured on rand128, 1 GiB): two runs per lane with interleaved lookups
 // (57-59 % against 65-67 %), groups handed out by a device-wide atomic counter (same-address
 // atomics serialise at ~16 ns and, returning through vmcnt, stall every wave's first fetch:
@@ -1303,6 +1302,73 @@ __device__ __forceinline__ uint4 run_piece(const RunIo& io, int c)
         *reinterpret_cast<uint4*>((io_).wr + 1024) = r1_;                          \
         *reinterpret_cast<uint4*>((io_).wr + 2048) = r2_;                          \
         *reinterpret_cast<uint4*>((io_).wr + 3072) = r3_;                          \
+    } while (0)
+
+// ---- the whole-line loader (so_runs) ----------------------------------------------------------
+// Load i (0..7) fetches the whole 128-byte lines of runs 8i .. 8i+7, lane = 8*(run in block) + piece:
+// eight lanes per line and every line requested by ONE instruction, so the loads can be non-temporal
+// like the tile kernels' (a streaming read runs at 7.0-7.1 TB/s with nt loads, 6.2-6.3 TB/s without —
+// and 6.05 TB/s = 75.6 % is what the half-line loader above reaches with the automaton compiled out,
+// whatever the run length, 128 bytes = fully contiguous wave-loads to 4096: its ceiling is the cache
+// policy, not the access pattern; there every line is touched by two instructions and the second has
+// to find it in cache).  Parking then stores with half the lanes per half (16 ds_write_b128 per line
+// instead of 8).  so_runs: 63-67 % -> 71-72 %.  kmp_runs, bound by its dependent lookups rather than
+// by the data path, lost 3 points to the extra stores and keeps the half-line loader.
+struct LineIo {
+    uint8_t* wr_e;       // where this lane parks its piece of an even-numbered load (+ 512*i)
+    uint8_t* wr_o;       // ... of an odd-numbered load
+    bool first_half;     // loader role: this lane's piece belongs to bytes 0..63 of the line
+    const uint8_t* rd;   // this lane's own run in the slab
+    uint32_t rswz;       // XOR applied to the piece offset 16*c when reading
+    uint32_t loff;       // loader role: byte offset of this lane's piece inside an 8-run block
+};
+
+__device__ __forceinline__ LineIo line_io(uint8_t* slab, uint32_t lane, uint32_t run_len)
+{
+    LineIo io;
+    const uint32_t c = lane & 7u, rb = lane >> 3;  // piece of the line, run inside the block
+    // slot of piece q (0..3 of the half) of run R: 4R + (q ^ ((R >> 2) & 3)); R = 8i + rb gives
+    // (R >> 2) & 3 = ((i & 1) << 1) | (rb >> 2)
+    const uint32_t q = c & 3u, t = rb >> 2;
+    io.wr_e = slab + (4u * rb + (q ^ t)) * 16u;
+    io.wr_o = slab + (4u * rb + (q ^ t ^ 2u)) * 16u;
+    io.first_half = c < 4u;
+    io.rd = slab + 64u * lane;
+    io.rswz = 16u * ((lane >> 2) & 3u);
+    io.loff = rb * run_len + 16u * c;
+    return io;
+}
+
+__device__ __forceinline__ uint4 run_piece(const LineIo& io, int c)
+{
+    return *reinterpret_cast<const uint4*>(io.rd + ((16u * c) ^ io.rswz));
+}
+
+#define LINE_FETCH(gbase_, blk_, off_)                                             \
+    do {                                                                           \
+        const uint8_t* p_ = (gbase_) + (off_);                                     \
+        n0 = ld_stream16(p_ + (blk_)[0]);                                          \
+        n1 = ld_stream16(p_ + (blk_)[1]);                                          \
+        n2 = ld_stream16(p_ + (blk_)[2]);                                          \
+        n3 = ld_stream16(p_ + (blk_)[3]);                                          \
+        n4 = ld_stream16(p_ + (blk_)[4]);                                          \
+        n5 = ld_stream16(p_ + (blk_)[5]);                                          \
+        n6 = ld_stream16(p_ + (blk_)[6]);                                          \
+        n7 = ld_stream16(p_ + (blk_)[7]);                                          \
+    } while (0)
+// park one 64-byte half of every run's line: the lanes holding pieces of that half store, the others idle
+#define LINE_PARK(io_, first_)                                                     \
+    do {                                                                           \
+        if ((io_).first_half == (first_)) {                                        \
+            *reinterpret_cast<uint4*>((io_).wr_e) = n0;                            \
+            *reinterpret_cast<uint4*>((io_).wr_o + 512) = n1;                      \
+            *reinterpret_cast<uint4*>((io_).wr_e + 1024) = n2;                     \
+            *reinterpret_cast<uint4*>((io_).wr_o + 1536) = n3;                     \
+            *reinterpret_cast<uint4*>((io_).wr_e + 2048) = n4;                     \
+            *reinterpret_cast<uint4*>((io_).wr_o + 2560) = n5;                     \
+            *reinterpret_cast<uint4*>((io_).wr_e + 3072) = n6;                     \
+            *reinterpret_cast<uint4*>((io_).wr_o + 3584) = n7;                     \
+        }                                                                          \
     } while (0)
 
 template <bool PREFIX>  // PREFIX: m > 255 — the automaton of the 255-byte prefix; hits are verified
@@ -1553,7 +1619,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
     const uint32_t m = a.m, w = m < 32 ? m : 32;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t* S = reinterpret_cast<uint32_t*>(smem);
-    const RunIo io = run_io(smem + 65536 + wave * kLineSlab, lane, run_len);
+    const LineIo io = line_io(smem + 65536 + wave * kLineSlab, lane, run_len);
     const uint32_t sentinel = AND ? 0u : 0xFFFFFFFFu << (32 - w);  // mask of a byte outside the lane's range
     const uint32_t one = 1u << (32 - w);                          // AND: the bit shifted in
     const uint32_t hinit = AND ? 0u : 0xFFFFFFFFu;                 // hit collector before any hit
@@ -1579,9 +1645,9 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
     const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
     for (uint64_t g = (uint64_t)blockIdx.x * kRunWaves + wave; g * 64 < nruns; g += nwaves) {
         const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
-        uint32_t blk[4];
+        uint32_t blk[8];  // a block that lies entirely past the last run re-reads block 0 (loaded, never consumed)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) blk[i] = g * 64 + 16 * i < nruns ? 16u * i * run_len : 0u;
+        for (int i = 0; i < 8; ++i) blk[i] = g * 64 + 8 * i < nruns ? 8u * i * run_len : 0u;
         const uint64_t my = g * 64 + lane;
         const uint64_t seg = (run_first + my) * run_len;
         const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
@@ -1591,7 +1657,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
         const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
 
         uint4 n0, n1, n2, n3, n4, n5, n6, n7;
-        RUN_FETCH(gbase, blk, 0u);
+        LINE_FETCH(gbase, blk, 0u);
         uint32_t D = sentinel;  // SO: all ones, SA: zero — no prefix matched yet
         bool parked = false;
         const uint8_t* parked_at = a.text;
@@ -1676,10 +1742,10 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
             }
         };
         for (uint32_t k = 0; k < nlines; ++k) {
-            RUN_PARK(io, n0, n1, n2, n3);
+            LINE_PARK(io, true);
             half(k * kRunLine);
-            RUN_PARK(io, n4, n5, n6, n7);
-            if (k + 1 < nlines) RUN_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
+            LINE_PARK(io, false);
+            if (k + 1 < nlines) LINE_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
             half(k * kRunLine + 64u);
         }
     }
@@ -2524,8 +2590,11 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             }
             if (g_tune[6] != 1 || algo == SMARTGPU_SA) {  // per-lane runs through LDS line slabs (tune[6]=1: LDS tiles, for A/B)
                 ScanArgs b = a;
-                b.so_off = kTableOff;
-                return launch_so_runs(b, algo == SMARTGPU_SA, num_cus, stream);
+                // Shift-And counts in the complemented (Shift-Or) form by default: api.cpp build_blob; its own
+                // AND form (so_runs<.., AND = true>, masks after the Shift-Or ones) with tune(6,3)
+                const bool and_form = algo == SMARTGPU_SA && g_tune[6] == 3;
+                b.so_off = and_form ? kTableOff + 1024 : kTableOff;
+                return launch_so_runs(b, and_form, num_cus, stream);
             }
             const size_t lds = 1040 + (size_t)kSoT * kSoL + 32;
             const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kSoT * kSoL);

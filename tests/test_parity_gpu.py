@@ -125,11 +125,12 @@ def test_packed_load_policies(oracle, policy):
         engine.tune(7, 0)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_alternate_serial_kernels(oracle, variant):
     """SO and KMP normally run on the bank-private / full-table runs kernels; the variants kept
     for A/B measurements must give the same counts: 1 = LDS tiles (so_scan, kmp_scan),
-    2 = shared-table so_runs and the failure-link kmp_links_runs."""
+    2 = shared-table so_runs and the failure-link kmp_links_runs, 3 = Shift-And in its own AND
+    form (by default it counts in the complemented, Shift-Or form)."""
     from smart_amd import engine
     engine.tune(6, variant)
     engine.tune(3, variant)
@@ -137,9 +138,9 @@ def test_alternate_serial_kernels(oracle, variant):
         for r in load_golden("fuzz_vectors.json")["rows"][::2]:
             P, T = fuzz_case(oracle, r)
             text = Text.upload(T)
-            got = gpu_counts(P, text, algos=("so", "kmp"))
+            got = gpu_counts(P, text, algos=("so", "kmp", "sa"))
             text.free()
-            assert got["so"] == r["count"] and got["kmp"] == r["count"], (r, got)
+            assert got["so"] == r["count"] and got["kmp"] == r["count"] and got["sa"] == r["count"], (r, got)
     finally:
         engine.tune(6, 0)
         engine.tune(3, 0)
