@@ -12,21 +12,39 @@ text.  The text is generated on the device (counter-based rand-sigma corpus,
 SURVEY.md §8d) and is resident in HBM before the timed region; every step's
 preprocessing (table build + upload = SMART's pre_time) is done before it as
 well, so the timed region is SMART's run_time: kernels + the reduction of the
-counts.  With N>1 ranks (one per GPU, torchrun) the text is N GiB sharded by
-byte offset with an (m-1)-byte overlap; the K counts are summed with ONE RCCL
-all-reduce inside the timed region ("scaling": "weak").
+counts.
 
-After the timed region every count is checked: against an independent kernel
-(EPSM packed matcher) for all K patterns and against the CPU oracle / the real
-reference build for the cpu_baseline sample.  A mismatch aborts the run.
+N > 1: one process per GPU.  Started plainly (`python bench.py --gpus N`, no
+WORLD_SIZE in the environment) this process launches the N ranks itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1 ...` BEFORE anything touches a GPU, relays their output and exits with
+their code; started under torchrun (the driver's way) it is one of the ranks.
+The text is N x --gib GiB sharded by byte offset with an (m-1)-byte overlap; the
+K counts are summed with ONE RCCL all-reduce inside the timed region
+("scaling": "weak").  `--gib 4` gives every GPU the 4 GiB shard of BASELINE
+configs 4-5.
+
+After the timed region every count is checked: against a kernel of a different
+family (the KMP automaton when the timed plans run on the packed matcher, the
+packed matcher otherwise) for all K patterns and against the real reference
+build / the CPU oracle for the cpu_baseline sample.  A mismatch aborts the run.
+
+At N = 1 the line also carries "sweep": every cell of BASELINE config 2
+(HOR/BM/KMP/SO/BNDM/EPSM x m in {4,8,32,256} on the 1 GiB rand128 text) and of
+config 3 (SO, BNDM x sigma in {2,4} x m in {2..64} on 1 GiB), each timed with HIP
+events over >= 12 launches, with the kernel that ran, its fraction of the 8 TB/s
+HBM peak and a count check; cells whose plans were rerouted to another kernel
+get a second entry on the algorithm's own kernel (smartgpu_tune(0,1)).
 """
 import argparse
+import collections
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -34,6 +52,9 @@ sys.path.insert(0, ROOT)
 SEED = 0x5EED0001        # corpus seed
 PATTERN_SALT = 0x0A77E2  # k_j = splitmix64(PATTERN_SALT + 4096*j + m) mod (n-m)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+OWN_KERNEL = {"hor": "hor_scan", "bm": "bm_scan", "kmp": "kmp_runs", "so": "so_runs", "bndm": "bndm_scan",
+              "epsm": "packed_scan"}
+KERNELS_HIP = os.path.join(ROOT, "smart_amd", "csrc", "kernels.hip")
 
 
 def splitmix64(x):
@@ -44,16 +65,44 @@ def splitmix64(x):
     return x ^ (x >> 31)
 
 
-def load_traffic(kernel, workload_key):
-    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/),
-    already corrected as MI355X_MICROARCH.md §HBM prescribes; None if absent."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def kernels_sha256():
+    with open(KERNELS_HIP, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def load_traffic(kernel, workload_key, path=None):
+    """(bytes, source) — HBM bytes per launch from the committed rocprofv3 --pmc pass (profiles/),
+    corrected as MI355X_MICROARCH.md §HBM prescribes.  The figure is only valid for the kernel
+    source it was profiled on: profiles/pmc_traffic.json records the sha256 of kernels.hip, and a
+    different source gives (None, why)."""
+    path = path or os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             table = json.load(f)
-        return table.get(kernel, {}).get(workload_key)
     except (OSError, ValueError):
-        return None
+        return None, "profiles/pmc_traffic.json is missing"
+    src = table.get("_source", {})
+    have = kernels_sha256()
+    if src.get("kernels_hip_sha256") != have:
+        return None, ("not measured for this kernel source: kernels.hip sha256 %s..., the PMC pass in %s was taken on %s..."
+                      % (have[:12], src.get("summary", "profiles/"), str(src.get("kernels_hip_sha256"))[:12]))
+    v = table.get(kernel, {}).get(workload_key)
+    if v is None:
+        return None, "no PMC pass for %s / %s" % (kernel, workload_key)
+    return v, "%s @ %s (kernels.hip sha256 %s...)" % (src.get("summary", "profiles/"), src.get("commit", "?"), have[:12])
+
+
+def launch_ranks(n):
+    """Plain `python bench.py --gpus N`: start the N ranks as children through torch.distributed.run.
+    Nothing in this process has touched a GPU (no HIP call, no torch import)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -65,18 +114,43 @@ def main():
     ap.add_argument("--plen", dest="m", type=int, default=32, help="pattern length m")
     ap.add_argument("--sigma", type=int, default=128)
     ap.add_argument("--gib", type=float, default=1.0, help="text GiB per GPU")
+    ap.add_argument("--corpus", default="rand", help="rand (counter-based rand<sigma>) or english "
+                    "(tests/golden/english_bible_world192.txt.xz tiled to --gib per GPU, BASELINE config 4)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the per-cell sweep of configs 2 and 3")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (needs --backend gloo); the numbers mean nothing")
+    ap.add_argument("--check-launch", action="store_true",
+                    help="ranks only rendezvous (gloo), all-reduce their rank ids and print what they see; no GPU needed")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    if args.check_launch:
+        import torch
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"check_launch": True, "n_gpus": world, "rank_id_sum": int(t[0]),
+                              "launched_by": "torch.distributed.run", "master_addr": os.environ.get("MASTER_ADDR")}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    import numpy as np
     import torch
     import smart_amd
     from smart_amd import Plan, Text, engine
@@ -113,10 +187,19 @@ def main():
     # total_n - m); it holds m-1 extra bytes so those windows are complete
     from smart_amd.sharding import weak_shard
     global_off, local_len = weak_shard(shard, m, rank, world)
-    text = Text.generate(SEED, args.sigma, local_len, off=global_off, device=local_rank)
+    english = None
+    if args.corpus == "english":
+        from smart_amd import corpus
+        english = corpus.english_unit()
+        text = Text.upload_tiled(english, local_len, phase=global_off % len(english), device=local_rank)
+    else:
+        text = Text.generate(SEED, args.sigma, local_len, off=global_off, device=local_rank)
 
-    # patterns: cut from the GLOBAL text at seeded offsets (any shard)
+    # patterns: cut from the GLOBAL text at seeded offsets (any shard); English: from the first copy
     def pattern(j):
+        if english is not None:
+            k = splitmix64(PATTERN_SALT + 4096 * j + m) % (len(english) - m)
+            return k, english[k:k + m].copy()
         k = splitmix64(PATTERN_SALT + 4096 * j + m) % (total_n - m)
         t = Text.generate(SEED, args.sigma, m, off=k, device=local_rank)
         p = t.read(0, m)
@@ -165,11 +248,19 @@ def main():
 
     # ---- verification (outside the timed region) -------------------------------
     got = got.numpy().astype(np.uint64)
+    kernel_hist = collections.Counter(plans[j].kernel_name for j in range(W, W + K))
+    main_kernel = kernel_hist.most_common(1)[0][0]
     check = torch.zeros(K, dtype=torch.int64, device="cuda")
-    other = "epsm" if algo != "epsm" else "hor"
+    others = []
     oplans = []
     for j in range(K):
+        # a kernel of another family than the one that produced the count
+        other = "kmp" if plans[W + j].kernel_name == "packed_scan" else "epsm"
+        if other == algo:
+            other = "so"
+        others.append(other)
         pl = Plan(other, pats[W + j][1], device=local_rank)
+        assert pl.kernel_name != plans[W + j].kernel_name, (pl.kernel_name, algo, other)
         pl.set_result_buffer(check.data_ptr() + 8 * j, 1)
         pl.launch(text, slot=0)
         oplans.append(pl)
@@ -177,9 +268,11 @@ def main():
     all_reduce_counts(check)
     want = check.cpu().numpy().astype(np.uint64)
     if not np.array_equal(got, want):
-        raise SystemExit("COUNT MISMATCH %s vs %s: %s != %s" % (algo, other, got.tolist(), want.tolist()))
+        raise SystemExit("COUNT MISMATCH %s vs %s: %s != %s" % (algo, sorted(set(others)), got.tolist(), want.tolist()))
     if int(got.min()) < 1:
         raise SystemExit("a planted pattern was not found: %s" % got.tolist())
+    for pl in oplans:
+        pl.free()
 
     # ---- CPU baseline (rank 0, N=1 only): SMART's own algorithm on host cores ---
     cpu = None
@@ -187,7 +280,8 @@ def main():
         from oracle import pyoracle
         pyoracle.build(ref=False)
         T = text.read(0, local_len)
-        assert np.array_equal(T[: 1 << 16], pyoracle.gen_text(SEED, args.sigma, 0, 1 << 16))
+        if english is None:
+            assert np.array_equal(T[: 1 << 16], pyoracle.gen_text(SEED, args.sigma, 0, 1 << 16))
         ref = None
         if algo in pyoracle.ALGOS and pyoracle.have_ref() and local_len < (1 << 31):
             ref = pyoracle.RefAlgo(algo)
@@ -220,6 +314,7 @@ def main():
             "all_cores": {"value": round(local_len / t_mt / 1e9, 3), "cores": cores, "kind": "port",
                           "sample": "1 pattern, text split by core with (m-1) overlap"},
         }
+        del T
 
     # per-pattern spread of the kernel time, as SMART reports mean/best/worst/std over a pattern set
     # (smart.c:347-351): a second, untimed pass over the same K plans with one event pair per launch
@@ -233,11 +328,25 @@ def main():
                   "note": "ms per pattern, separate pass after the timed region, HIP events per launch"}
 
     read_probe = engine.probe_read_gbs(text) if rank == 0 else None
+    for pl in plans:
+        pl.free()
+
+    # ---- per-cell sweep of BASELINE configs 2 and 3 (N = 1) ---------------------
+    sweep = None
+    if rank == 0 and world == 1 and not args.no_sweep and english is None:
+        sweep = run_sweep(text if (args.sigma == 128 and local_len == 1 << 30) else None, local_rank)
+    text.free()
+
     if rank == 0:
         bytes_per_launch = local_len                       # algorithmic bytes: every text byte once
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        workload = "%s m=%d, %.2f GiB rand%d per GPU" % (algo.upper(), m, args.gib, args.sigma)
-        traffic = load_traffic(plans[0].kernel_name, "%s_m%d_sigma%d_gib%g" % (algo, m, args.sigma, args.gib))
+        if english is not None:
+            workload = "%s m=%d, English (bible.txt||world192.txt, %d B) tiled to %.2f GiB per GPU" % (algo.upper(), m, len(english), args.gib)
+            key = "%s_m%d_english_gib%g" % (algo, m, args.gib)
+        else:
+            workload = "%s m=%d, %.2f GiB rand%d per GPU" % (algo.upper(), m, args.gib, args.sigma)
+            key = "%s_m%d_sigma%d_gib%g" % (algo, m, args.sigma, args.gib)
+        traffic, traffic_source = load_traffic(main_kernel, key)
         out = {
             "metric": "GB/s text scanned per GPU (bit-exact occ count), m=32 on 1 GiB rand128",
             "value": round(total_n * K / elapsed / 1e9, 2),
@@ -245,26 +354,117 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed * 1e3 / K, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload, "algorithm": algo, "m": m, "sigma": args.sigma,
+            "dtype": "u8", "data": "synthetic" if english is None else "reference corpus (englishTexts), tiled",
+            "config": {"workload": workload, "algorithm": algo, "m": m, "sigma": args.sigma if english is None else None,
                        "text_bytes_per_gpu": local_len, "patterns": K,
-                       "corpus": "counter-based splitmix64 rand-sigma, seed 0x5EED0001, generated on device",
-                       "sharding": "byte offset, (m-1) overlap, one RCCL all-reduce of the K counts" if world > 1 else "single GPU",
+                       "corpus": ("counter-based splitmix64 rand-sigma, seed 0x5EED0001, generated on device" if english is None
+                                  else "bible.txt||world192.txt as getText loads it (smart.c:95-138), tiled on device"),
+                       "sharding": ("byte offset, (m-1) overlap, one RCCL all-reduce of the K counts over %d ranks (%s)"
+                                    % (world, args.backend)) if world > 1 else "single GPU",
+                       "ranks": world,
                        "pre_ms_per_pattern": round(pre_ms, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": plans[0].kernel_name, "kernel_ms": round(kernel_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": main_kernel, "kernels_of_the_timed_plans": dict(kernel_hist),
+                         "kernel_ms": round(kernel_ms, 4),
                          "bytes_per_launch": bytes_per_launch, "kernel_ms_per_pattern": spread,
                          "measured_stream_read_GBps": round(read_probe, 1),
                          "frac_of_measured_stream_read": round(achieved / read_probe, 4)},
             "cpu_baseline": cpu,
-            "counts_verified": "all %d counts equal the %s kernel%s" % (K, other, " and the CPU sample" if cpu else ""),
+            "counts_verified": "all %d counts equal a kernel of another family (%s)%s"
+                               % (K, "/".join(sorted(set(others))), " and the CPU sample" if cpu else ""),
         }
+        if sweep is not None:
+            out["sweep"] = sweep["cells"]
+            out["min_frac"] = sweep["min_frac"]
+            out["sweep_note"] = sweep["note"]
         print(json.dumps(out))
 
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_sweep(text128, device):
+    """Cells of BASELINE config 2 (six algorithms x m in {4,8,32,256}, 1 GiB rand128) and config 3
+    (SO and BNDM x sigma in {2,4} x m in {2,4,8,16,32,64}, 1 GiB), the harness loop of
+    src/smart.c:290-345 reduced to what it times: per cell 3 patterns x 4 launches between two HIP
+    events on the launch stream.  Every cell names the kernel its plans launched; a cell whose plans
+    were rerouted (api.cpp build_blob) is measured again on the algorithm's own kernel."""
+    import numpy as np
+    import smart_amd
+    from smart_amd import Plan, Text, engine
+
+    n = 1 << 30
+    J, REPS = 3, 4
+    cells = []
+    ref_counts = {}
+
+    def time_cell(text, sigma, algo, m, pats, own):
+        if own:
+            engine.tune(0, 1)
+        try:
+            plans = [Plan(algo, p, device=device) for p in pats]
+            kernels = collections.Counter(pl.kernel_name for pl in plans)
+            plans[0].launch(text, slot=1)  # warm-up (code object, LDS attribute)
+            engine.device_sync(device)
+            engine.stream_mark(device, 0)
+            for r in range(REPS):
+                for pl in plans:
+                    pl.launch(text, slot=0)
+            engine.stream_mark(device, 1)
+            ms = engine.stream_elapsed_ms(device) / (REPS * len(plans))
+            counts = [pl.result(0)[0] // REPS for pl in plans]
+        finally:
+            if own:
+                engine.tune(0, 0)
+        # the reference count: a kernel of another family (the automaton for packed plans, else the packed matcher)
+        ok = True
+        for j, (p, pl) in enumerate(zip(pats, plans)):
+            fam = "kmp" if pl.kernel_name == "packed_scan" else "epsm"
+            key = (sigma, m, j, fam)
+            if key not in ref_counts:
+                ref_counts[key] = smart_amd.search(fam, p, text)[0]
+            ok = ok and counts[j] == ref_counts[key] and counts[j] >= 1
+        for pl in plans:
+            pl.free()
+        kernel = kernels.most_common(1)[0][0]
+        cell = {"algo": algo, "m": m, "sigma": sigma, "kernel": kernel, "ms": round(ms, 4),
+                "frac": round(n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "count_ok": bool(ok)}
+        if len(kernels) > 1:
+            cell["kernels"] = dict(kernels)
+        if own:
+            cell["own_kernel"] = True  # smartgpu_tune(0,1): the algorithm's own kernel, not the plan's choice
+        return cell
+
+    def cells_for(text, sigma, algos, ms):
+        for m in ms:
+            pats = [text.pattern(splitmix64(PATTERN_SALT + 4096 * j + m) % (n - m), m) for j in range(J)]
+            for algo in algos:
+                c = time_cell(text, sigma, algo, m, pats, own=False)
+                cells.append(c)
+                if c["kernel"] != OWN_KERNEL[algo] or "kernels" in c:
+                    cells.append(time_cell(text, sigma, algo, m, pats, own=True))
+
+    own128 = text128 is None
+    if own128:
+        text128 = Text.generate(SEED, 128, n, device=device)
+    cells_for(text128, 128, ("hor", "bm", "kmp", "so", "bndm", "epsm"), (4, 8, 32, 256))
+    if own128:
+        text128.free()
+    for sigma in (4, 2):
+        t = Text.generate(SEED, sigma, n, device=device)
+        cells_for(t, sigma, ("so", "bndm"), (2, 4, 8, 16, 32, 64))
+        t.free()
+    bad = [c for c in cells if not c["count_ok"]]
+    if bad:
+        raise SystemExit("SWEEP COUNT MISMATCH: %s" % bad)
+    north = [c["frac"] for c in cells if c["sigma"] == 128 and not c.get("own_kernel")]
+    return {"cells": cells,
+            "min_frac": {"rand128_m4to256_plan_choice": min(north),
+                         "all_cells": min(c["frac"] for c in cells)},
+            "note": "1 GiB per cell; ms = HIP events over %d launches (%d patterns x %d); frac = 2^30 B / ms / 8 TB/s; "
+                    "own_kernel = measured again with smartgpu_tune(0,1) because the plan rerouted the pattern" % (J * REPS, J, REPS)}
 
 
 if __name__ == "__main__":

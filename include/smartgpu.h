@@ -104,6 +104,21 @@ int smartgpu_text_read(const smartgpu_text *t, uint64_t off, uint64_t len, void 
 int smartgpu_search64(int algo, const uint8_t *P, uint32_t m, const smartgpu_text *text,
                       uint64_t off, uint64_t n, uint64_t *count, double *pre_ms, double *run_ms);
 
+/* The harness's inner loop as ONE call (src/smart.c:312-345: for each of the -pset patterns of a length,
+ * execute() and read count and times back): K patterns of m bytes each, P[0..K), over the same resident
+ * text range.  Preprocessing: the K tables are built on the host and placed in one arena in HBM (grown
+ * when a batch needs more, never allocated per pattern); searching: K launches back to back on the
+ * device's stream and ONE read-back of the K counts, so the synchronous per-call cost of
+ * smartgpu_search64 (25-30 us) is paid once per pattern set.
+ *   counts[k]   occurrences of P[k]                                   (K entries, required)
+ *   pre_ms[k]   host table construction of P[k] + its share of the upload     (K entries or NULL)
+ *   run_ms[k]   device time of the k-th search by HIP events — one event per pattern — (K entries or NULL:
+ *               no per-pattern events)
+ *   *batch_ms   wall clock from the first launch to the counts on the host   (or NULL)              */
+int smartgpu_search_batch64(int algo, const uint8_t *const *P, uint32_t m, uint32_t K, const smartgpu_text *text,
+                            uint64_t off, uint64_t n, uint64_t *counts, double *pre_ms, double *run_ms,
+                            double *batch_ms);
+
 /* SMART's own plugin shape, one symbol per algorithm (main.h:39).  T is a HOST
  * pointer: the text is uploaded for the call and released afterwards, so this
  * is the compatibility path, not the fast one.  Returns the count, or -1 when
@@ -186,6 +201,11 @@ int smartgpu_mtext_ngpus(const smartgpu_mtext *t);
 #define SMARTGPU_REDUCE_HOST 1
 int smartgpu_msearch64(int algo, const uint8_t *P, uint32_t m, smartgpu_mtext *text, int reduce,
                        uint64_t *count, double *pre_ms, double *run_ms);
+
+/* The pattern-set form of smartgpu_msearch64: every device searches its shard for all K patterns, then ONE
+ * reduction of the K counts (RCCL: one ncclAllReduce of K uint64 per device, in place) and one read-back. */
+int smartgpu_msearch_batch64(int algo, const uint8_t *const *P, uint32_t m, uint32_t K, smartgpu_mtext *text,
+                             int reduce, uint64_t *counts, double *pre_ms, double *batch_ms);
 
 /* ---- stream timing (hipEvents on the stream the kernels run on) ------------ */
 int smartgpu_stream_mark(int device, int which /* 0 = begin, 1 = end */);

@@ -5,4 +5,4 @@ The product is the C-ABI shared library `smart_amd/csrc/libsmartgpu.so`
 mirror of SMART's harness vocabulary (texts, patterns, algorithms).
 """
 from .engine import (ALGOS, MIN_M, MultiText, Plan, SmartGpuError, Text, algo_id, build_table, device_count, kernel_for,  # noqa: F401
-                     find, lib, search, search_host, version)
+                     find, lib, search, search_batch, search_host, version)

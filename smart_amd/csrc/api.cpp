@@ -54,6 +54,14 @@ struct DeviceCtx {
     size_t pinned_bytes = 0;
     unsigned long long* pinned_count = nullptr;  // 8-byte readback slot
     hipEvent_t mark[2] = {nullptr, nullptr};     // smartgpu_stream_mark()
+    // smartgpu_search_batch64(): one arena for the K pattern blobs and the K counts, grown when a
+    // batch needs more, never per pattern; K+1 events for the per-pattern device times
+    uint8_t* arena = nullptr;
+    size_t arena_bytes = 0;
+    unsigned long long* batch_counts = nullptr;
+    size_t batch_slots = 0;
+    unsigned long long* pinned_counts = nullptr;  // host side of the one read-back
+    std::vector<hipEvent_t> batch_events;
 };
 DeviceCtx g_dev[kMaxDevices];
 
@@ -273,6 +281,33 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
                     const uint32_t r = id(st);
                     for (uint32_t c = 0; c < 256; ++c) sw[r * 256 + (c ^ r)] = static_cast<uint8_t>(id(dfa[st * 256 + c]));
                 }
+                append(sw.data(), sw.size());
+            }
+            {   // kmp_runs: the same automaton over w = min(m, 254) bytes with an ABSORBING accept row Z.  Every
+                // transition into the accept state w leads to Z, Z leads to Z; row id(w) holds the real
+                // delta(w, .).  Z = id(w) + 1 is the largest id in use (the kernel's min(next, id(w)) turns Z
+                // back into the accept state).  Fewer than 63 states: id(s) = 4s, Z = 4w + 1, the table ends
+                // there.  Otherwise id(s) = rotl8(s, 2), id(w) = 254, Z = 255; rotl8 maps only s = 191 to 254
+                // and only s = 255 to 255, so state 191 (if there is one besides w) takes the slot w gave up.
+                const uint32_t w = std::min<uint32_t>(m, sg::kKmpWindow);
+                const std::vector<uint8_t> dfa = sg::kmp_dfa(P, w);
+                const bool small = w < 63;
+                const uint32_t idw = small ? 4 * w : 254u, Z = idw + 1;
+                auto rot = [](uint32_t st) { return ((st << 2) | (st >> 6)) & 255u; };
+                auto id = [&](uint32_t st) {
+                    if (st == w) return idw;
+                    if (small) return 4 * st;
+                    return (st == 191) ? rot(w) : rot(st);
+                };
+                std::vector<uint8_t> sw(256 * 256, 0);
+                for (uint32_t st = 0; st <= w; ++st) {
+                    const uint32_t r = id(st);
+                    for (uint32_t c = 0; c < 256; ++c) {
+                        const uint32_t nx = dfa[st * 256 + c];
+                        sw[r * 256 + (c ^ r)] = static_cast<uint8_t>(nx == w ? Z : id(nx));
+                    }
+                }
+                for (uint32_t c = 0; c < 256; ++c) sw[Z * 256 + (c ^ Z)] = static_cast<uint8_t>(Z);
                 append(sw.data(), sw.size());
             }
             break;
@@ -736,6 +771,150 @@ int smartgpu_search64(int algo, const uint8_t* P, uint32_t m, const smartgpu_tex
     return SMARTGPU_OK;
 }
 
+
+/* ---- a whole pattern set per call (the harness loop, src/smart.c:312-345) ------------- */
+}  // extern "C"
+
+namespace {
+
+// make sure the device's batch arena holds `blob_bytes` of tables and `k` counts
+bool batch_reserve(DeviceCtx* d, size_t blob_bytes, size_t k)
+{
+    if (blob_bytes > d->arena_bytes) {
+        if (d->arena) (void)hipFree(d->arena);
+        d->arena = nullptr;
+        d->arena_bytes = 0;
+        const size_t want = std::max(blob_bytes + blob_bytes / 4, size_t(8) << 20);
+        if (hipMalloc(reinterpret_cast<void**>(&d->arena), want) != hipSuccess) { set_error("batch arena: hipMalloc of %zu bytes failed", want); return false; }
+        d->arena_bytes = want;
+    }
+    if (k > d->batch_slots) {
+        if (d->batch_counts) (void)hipFree(d->batch_counts);
+        if (d->pinned_counts) (void)hipHostFree(d->pinned_counts);
+        d->batch_counts = nullptr;
+        d->pinned_counts = nullptr;
+        d->batch_slots = 0;
+        const size_t want = std::max<size_t>(k, 1024);
+        if (hipMalloc(reinterpret_cast<void**>(&d->batch_counts), want * 8) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&d->pinned_counts), want * 8, hipHostMallocDefault) != hipSuccess) {
+            set_error("batch counts: allocation of %zu slots failed", want);
+            return false;
+        }
+        d->batch_slots = want;
+    }
+    return true;
+}
+
+struct BatchPlan { uint32_t halo, prefer_packed, sparse, so_off; size_t off; };
+
+// Build the K blobs on the host and place them in the device's arena; pre_ms[k] = host table construction of
+// pattern k + its share of the upload.  plans[k].off = offset of blob k in the arena.
+int batch_upload(DeviceCtx* d, int algo, const uint8_t* const* P, uint32_t m, uint32_t K, std::vector<BatchPlan>& plans,
+                 double* pre_ms)
+{
+    std::vector<std::vector<uint8_t>> blobs(K);
+    std::vector<double> host_ms(K, 0.0);
+    size_t total = 0;
+    plans.resize(K);
+    for (uint32_t k = 0; k < K; ++k) {
+        if (!P[k]) { set_error("pattern %u is NULL", k); return SMARTGPU_ERR_ARG; }
+        const double t0 = now_ms();
+        blobs[k] = build_blob(algo, P[k], m, &plans[k].halo, &plans[k].prefer_packed, &plans[k].sparse, &plans[k].so_off);
+        host_ms[k] = now_ms() - t0;
+        plans[k].off = total;
+        total += blobs[k].size();  // multiples of 256
+    }
+    if (!batch_reserve(d, total, K)) return SMARTGPU_ERR_NOMEM;
+    const double t_up = now_ms();
+    // pinned staging -> arena, as many blobs per copy as the staging buffer holds
+    for (uint32_t k = 0; k < K;) {
+        size_t fill = 0;
+        uint32_t j = k;
+        while (j < K && fill + blobs[j].size() <= d->pinned_bytes) {
+            std::memcpy(d->pinned + fill, blobs[j].data(), blobs[j].size());
+            fill += blobs[j].size();
+            ++j;
+        }
+        if (j == k) { set_error("a table blob of %zu bytes exceeds the staging buffer", blobs[k].size()); return SMARTGPU_ERR_NOMEM; }
+        if (hipMemcpyAsync(d->arena + plans[k].off, d->pinned, fill, hipMemcpyHostToDevice, d->stream) != hipSuccess ||
+            hipStreamSynchronize(d->stream) != hipSuccess) {
+            set_error("batch: table upload failed (%s)", hipGetErrorString(hipGetLastError()));
+            return SMARTGPU_ERR_HIP;
+        }
+        k = j;
+    }
+    const double up_ms = (now_ms() - t_up) / K;
+    if (pre_ms)
+        for (uint32_t k = 0; k < K; ++k) pre_ms[k] = host_ms[k] + up_ms;
+    return SMARTGPU_OK;
+}
+
+sg::ScanArgs batch_args(const BatchPlan& bp, const DeviceCtx* d, uint32_t m, const smartgpu_text* text, uint64_t off, uint64_t n,
+                        unsigned long long* slot)
+{
+    sg::ScanArgs a;
+    a.text = text->data();
+    a.s_begin = off;
+    a.s_end = (n >= m) ? off + n - m + 1 : off;
+    a.m = m;
+    a.halo = bp.halo;
+    a.fp_off = 0;
+    a.prefer_packed = bp.prefer_packed;
+    a.sparse = bp.sparse;
+    a.so_off = bp.so_off;
+    a.blob = d->arena + bp.off;
+    a.count = slot;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smartgpu_search_batch64(int algo, const uint8_t* const* P, uint32_t m, uint32_t K, const smartgpu_text* text,
+                            uint64_t off, uint64_t n, uint64_t* counts, double* pre_ms, double* run_ms, double* batch_ms)
+{
+    if (!P || K < 1 || !counts) { set_error("batch: P/counts NULL or K = 0"); return SMARTGPU_ERR_ARG; }
+    const int rc = check_search_args(algo, P[0], m, text, off, n);
+    if (rc != SMARTGPU_OK) return rc;
+    DeviceCtx* d = device_ctx(text->device);
+    if (!d) return SMARTGPU_ERR_HIP;
+    std::vector<BatchPlan> plans;
+    const int up = batch_upload(d, algo, P, m, K, plans, pre_ms);  // preprocessing phase
+    if (up != SMARTGPU_OK) return up;
+    const bool timed = run_ms != nullptr;
+    if (timed)
+        while (d->batch_events.size() < static_cast<size_t>(K) + 1) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e), return SMARTGPU_ERR_HIP);
+            d->batch_events.push_back(e);
+        }
+    // searching phase: K launches back to back, one read-back
+    const double t0 = now_ms();
+    HIP_TRY(hipMemsetAsync(d->batch_counts, 0, static_cast<size_t>(K) * 8, d->stream), return SMARTGPU_ERR_HIP);
+    if (timed) HIP_TRY(hipEventRecord(d->batch_events[0], d->stream), return SMARTGPU_ERR_HIP);
+    for (uint32_t k = 0; k < K; ++k) {
+        const sg::ScanArgs a = batch_args(plans[k], d, m, text, off, n, d->batch_counts + k);
+        HIP_TRY(sg::launch_scan(algo, a, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
+        if (timed) HIP_TRY(hipEventRecord(d->batch_events[k + 1], d->stream), return SMARTGPU_ERR_HIP);
+    }
+    HIP_TRY(hipMemcpyAsync(d->pinned_counts, d->batch_counts, static_cast<size_t>(K) * 8, hipMemcpyDeviceToHost, d->stream),
+            return SMARTGPU_ERR_HIP);
+    HIP_TRY(hipStreamSynchronize(d->stream), return SMARTGPU_ERR_HIP);
+    const double wall = now_ms() - t0;
+    for (uint32_t k = 0; k < K; ++k) counts[k] = d->pinned_counts[k];
+    if (timed)
+        for (uint32_t k = 0; k < K; ++k) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, d->batch_events[k], d->batch_events[k + 1]), return SMARTGPU_ERR_HIP);
+            run_ms[k] = ms;
+        }
+    if (batch_ms) *batch_ms = wall;
+    g_last_pre_ms = pre_ms ? pre_ms[K - 1] : 0.0;
+    g_last_run_ms = wall / K;
+    return SMARTGPU_OK;
+}
+
 /* ---- occurrence positions ------------------------------------------------- */
 int smartgpu_find64(const uint8_t* P, uint32_t m, const smartgpu_text* text, uint64_t off, uint64_t n,
                     uint64_t* positions, uint64_t cap, uint64_t* count)
@@ -859,7 +1038,6 @@ struct smartgpu_mtext {
     std::vector<smartgpu_text*> shards;   // shard g = bytes [begin[g], begin[g+1] + overlap)
     std::vector<uint64_t> begin;          // k+1 entries, start-position ownership
     std::vector<void*> comms;             // RCCL communicators, created on first RCCL reduce
-    std::vector<unsigned long long*> sums;  // per-device 8-byte reduce buffers
 };
 
 namespace {
@@ -919,10 +1097,6 @@ void smartgpu_mtext_free(smartgpu_mtext* t)
 {
     if (!t) return;
     for (smartgpu_text* s : t->shards) smartgpu_text_free(s);
-    for (size_t g = 0; g < t->sums.size(); ++g) {
-        hipSetDevice(t->devices[g]);
-        hipFree(t->sums[g]);
-    }
     for (void* c : t->comms)
         if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
     delete t;
@@ -931,88 +1105,102 @@ void smartgpu_mtext_free(smartgpu_mtext* t)
 uint64_t smartgpu_mtext_length(const smartgpu_mtext* t) { return t ? t->n : 0; }
 int smartgpu_mtext_ngpus(const smartgpu_mtext* t) { return t ? static_cast<int>(t->devices.size()) : 0; }
 
-int smartgpu_msearch64(int algo, const uint8_t* P, uint32_t m, smartgpu_mtext* text, int reduce,
-                       uint64_t* count, double* pre_ms, double* run_ms)
+int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint32_t K, smartgpu_mtext* text, int reduce,
+                             uint64_t* counts, double* pre_ms, double* batch_ms)
 {
     if (!text) { set_error("text handle is NULL"); return SMARTGPU_ERR_ARG; }
+    if (!P || K < 1 || !counts || !P[0]) { set_error("batch: P/counts NULL or K = 0"); return SMARTGPU_ERR_ARG; }
     if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS) { set_error("unknown algorithm id %d", algo); return SMARTGPU_ERR_ARG; }
     if (m < min_pattern(algo)) { set_error("%s: not applicable for m < %u", kAlgoNames[algo], min_pattern(algo)); return SMARTGPU_NA; }
-    if (!P || m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return SMARTGPU_ERR_ARG; }
+    if (m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return SMARTGPU_ERR_ARG; }
     const int k = static_cast<int>(text->devices.size());
-    // preprocessing: the tables are placed on every device
-    const double t_pre = now_ms();
-    std::vector<smartgpu_plan*> plans(k, nullptr);
-    auto cleanup = [&]() { for (smartgpu_plan* p : plans) smartgpu_plan_free(p); };
+    // preprocessing: the K tables are placed on every device (pre_ms: of the last device, they are equal work)
+    std::vector<std::vector<BatchPlan>> plans(k);
+    std::vector<DeviceCtx*> ctx(k, nullptr);
     for (int g = 0; g < k; ++g) {
-        plans[g] = smartgpu_plan_create(algo, P, m, text->devices[g]);
-        if (!plans[g]) { cleanup(); return SMARTGPU_ERR_HIP; }
+        ctx[g] = device_ctx(text->devices[g]);
+        if (!ctx[g]) return SMARTGPU_ERR_HIP;
+        const int up = batch_upload(ctx[g], algo, P, m, K, plans[g], pre_ms);
+        if (up != SMARTGPU_OK) return up;
     }
-    const double pre = now_ms() - t_pre;
-    if (reduce == SMARTGPU_REDUCE_RCCL) {
-        if (text->comms.empty()) {
-            if (!g_rccl.load()) { cleanup(); return SMARTGPU_ERR_HIP; }
-            text->comms.assign(k, nullptr);
-            if (g_rccl.CommInitAll(text->comms.data(), k, text->devices.data()) != 0) {
-                set_error("ncclCommInitAll failed (devices must be distinct)");
-                text->comms.clear();
-                cleanup();
-                return SMARTGPU_ERR_HIP;
-            }
-        }
-        if (text->sums.empty()) {
-            text->sums.assign(k, nullptr);
-            for (int g = 0; g < k; ++g) {
-                hipSetDevice(text->devices[g]);
-                if (hipMalloc(reinterpret_cast<void**>(&text->sums[g]), 8) != hipSuccess) {
-                    set_error("hipMalloc of the reduce buffer failed");
-                    cleanup();
-                    return SMARTGPU_ERR_NOMEM;
-                }
-            }
+    if (reduce == SMARTGPU_REDUCE_RCCL && text->comms.empty()) {
+        if (!g_rccl.load()) return SMARTGPU_ERR_HIP;
+        text->comms.assign(k, nullptr);
+        if (g_rccl.CommInitAll(text->comms.data(), k, text->devices.data()) != 0) {
+            set_error("ncclCommInitAll failed (devices must be distinct)");
+            text->comms.clear();
+            return SMARTGPU_ERR_HIP;
         }
     }
-    // searching: every shard on its own device / stream, concurrently
+    // searching: every shard on its own device / stream, concurrently; the same device listed twice (host reduce,
+    // the one-GPU test of the shard arithmetic) shares one arena, so its shards take turns
     const double t_run = now_ms();
-    int rc = SMARTGPU_OK;
-    for (int g = 0; g < k && rc == SMARTGPU_OK; ++g) {
+    std::vector<uint64_t> total(K, 0);
+    const bool distinct = reduce == SMARTGPU_REDUCE_RCCL;
+    auto launch_shard = [&](int g) -> int {
+        DeviceCtx* d = ctx[g];
+        HIP_TRY(hipSetDevice(text->devices[g]), return SMARTGPU_ERR_HIP);
+        HIP_TRY(hipMemsetAsync(d->batch_counts, 0, static_cast<size_t>(K) * 8, d->stream), return SMARTGPU_ERR_HIP);
         // shard g counts the starts it owns: its first (begin[g+1]-begin[g]) positions
         const uint64_t own = text->begin[g + 1] - text->begin[g];
         const uint64_t have = smartgpu_text_length(text->shards[g]);
         const uint64_t span = std::min<uint64_t>(have, own + m - 1);
-        rc = smartgpu_plan_launch(plans[g], text->shards[g], 0, span, 0, 0);
-    }
-    uint64_t total = 0;
-    if (rc == SMARTGPU_OK && reduce == SMARTGPU_REDUCE_RCCL) {
+        for (uint32_t j = 0; j < K; ++j) {
+            const sg::ScanArgs a = batch_args(plans[g][j], d, m, text->shards[g], 0, span, d->batch_counts + j);
+            HIP_TRY(sg::launch_scan(algo, a, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
+        }
+        return SMARTGPU_OK;
+    };
+    int rc = SMARTGPU_OK;
+    if (distinct) {
+        for (int g = 0; g < k && rc == SMARTGPU_OK; ++g) rc = launch_shard(g);
+        if (rc != SMARTGPU_OK) return rc;
+        // ONE collective for the whole pattern set: the K counts of every device, summed in place
         g_rccl.GroupStart();
-        for (int g = 0; g < k; ++g) {
-            DeviceCtx* d = device_ctx(text->devices[g]);
-            g_rccl.AllReduce(plans[g]->slot_ptr(0), text->sums[g], 1, kNcclUint64, kNcclSum, text->comms[g], d->stream);
-        }
-        if (g_rccl.GroupEnd() != 0) { set_error("RCCL all-reduce failed"); rc = SMARTGPU_ERR_HIP; }
-        if (rc == SMARTGPU_OK) {
-            DeviceCtx* d0 = device_ctx(text->devices[0]);
-            if (hipMemcpyAsync(d0->pinned_count, text->sums[0], 8, hipMemcpyDeviceToHost, d0->stream) != hipSuccess ||
-                hipStreamSynchronize(d0->stream) != hipSuccess) {
-                set_error("read-back of the reduced count failed");
-                rc = SMARTGPU_ERR_HIP;
-            } else {
-                total = *d0->pinned_count;
+        for (int g = 0; g < k; ++g)
+            g_rccl.AllReduce(ctx[g]->batch_counts, ctx[g]->batch_counts, K, kNcclUint64, kNcclSum, text->comms[g], ctx[g]->stream);
+        if (g_rccl.GroupEnd() != 0) { set_error("RCCL all-reduce failed"); return SMARTGPU_ERR_HIP; }
+        HIP_TRY(hipSetDevice(text->devices[0]), return SMARTGPU_ERR_HIP);
+        HIP_TRY(hipMemcpyAsync(ctx[0]->pinned_counts, ctx[0]->batch_counts, static_cast<size_t>(K) * 8, hipMemcpyDeviceToHost, ctx[0]->stream),
+                return SMARTGPU_ERR_HIP);
+        HIP_TRY(hipStreamSynchronize(ctx[0]->stream), return SMARTGPU_ERR_HIP);
+        for (uint32_t j = 0; j < K; ++j) total[j] = ctx[0]->pinned_counts[j];
+        for (int g = 1; g < k; ++g) smartgpu_device_sync(text->devices[g]);
+    } else {
+        for (int g = 0; g < k; ++g) {  // K-count read-backs added on the host
+            // (a device listed more than once re-uploads its tables: the arena is per device)
+            if (g > 0 && ctx[g] == ctx[g - 1]) {
+                const int up = batch_upload(ctx[g], algo, P, m, K, plans[g], nullptr);
+                if (up != SMARTGPU_OK) return up;
             }
-            for (int g = 1; g < k; ++g) smartgpu_device_sync(text->devices[g]);
-        }
-    } else if (rc == SMARTGPU_OK) {
-        for (int g = 0; g < k && rc == SMARTGPU_OK; ++g) {
-            uint64_t c = 0;
-            rc = smartgpu_plan_result(plans[g], 0, &c, nullptr);
-            total += c;
+            rc = launch_shard(g);
+            if (rc != SMARTGPU_OK) return rc;
+            DeviceCtx* d = ctx[g];
+            HIP_TRY(hipMemcpyAsync(d->pinned_counts, d->batch_counts, static_cast<size_t>(K) * 8, hipMemcpyDeviceToHost, d->stream),
+                    return SMARTGPU_ERR_HIP);
+            HIP_TRY(hipStreamSynchronize(d->stream), return SMARTGPU_ERR_HIP);
+            for (uint32_t j = 0; j < K; ++j) total[j] += d->pinned_counts[j];
         }
     }
     const double run = now_ms() - t_run;
-    cleanup();
+    for (uint32_t j = 0; j < K; ++j) counts[j] = total[j];
+    if (batch_ms) *batch_ms = run;
+    g_last_pre_ms = pre_ms ? pre_ms[K - 1] : 0.0;
+    g_last_run_ms = run / K;
+    return SMARTGPU_OK;
+}
+
+int smartgpu_msearch64(int algo, const uint8_t* P, uint32_t m, smartgpu_mtext* text, int reduce,
+                       uint64_t* count, double* pre_ms, double* run_ms)
+{
+    if (!P) { set_error("pattern is NULL"); return SMARTGPU_ERR_ARG; }
+    const uint8_t* one[1] = {P};
+    uint64_t c = 0;
+    double pre = 0.0, run = 0.0;
+    const int rc = smartgpu_msearch_batch64(algo, one, m, 1, text, reduce, &c, &pre, &run);
     if (rc != SMARTGPU_OK) return rc;
-    g_last_pre_ms = pre;
-    g_last_run_ms = run;
-    if (count) *count = total;
+    // (the per-device shards of the host-reduce path prepare their tables in turn: pre covers the last device)
+    if (count) *count = c;
     if (pre_ms) *pre_ms = pre;
     if (run_ms) *run_ms = run;
     return SMARTGPU_OK;

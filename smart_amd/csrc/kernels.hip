@@ -14,7 +14,7 @@
 //     tile; a lane verifies right-to-left through the halo by itself and — only for
 //     m-1 > H and only after H+1 bytes matched — parks the window for a
 //     wave-cooperative comparison of the rest (wave_verify).
-//  2. RUNS THROUGH LDS SLABS — the serial automata SO and KMP (so_runs, kmp_runs).
+//  2. RUNS THROUGH LDS SLABS — the serial automata SO and KMP (so_runs1, kmp_runs1).
 //     A lane owns a run of >= 512 start positions; the wave fetches the next 64 bytes
 //     of each of its 64 runs with four coalesced loads into its own LDS slab and every
 //     lane reads its run back.  No workgroup barrier.
@@ -28,6 +28,9 @@
 // so_scan / kmp_scan (LDS tiles for the serial automata) and hor_scan_bp (bank-private
 // LDS layout) are earlier designs kept selectable for A/B runs (smartgpu_tune).
 #include "kernels.hpp"
+
+#include <map>
+#include <utility>
 
 #include "../../include/smartgpu.h"
 
@@ -1162,7 +1165,7 @@ __global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a, uint64_t tile_fi
 // bytes back.  No workgroup barrier: a wave's DS operations execute in order.
 // The next step's loads are issued before the current step is processed.
 //
-// kmp_runs: the failure function (kmp.c:27-41) is expanded on the host into the automaton's
+// kmp_runs1: the failure function (kmp.c:27-41) is expanded on the host into the automaton's
 // transition table delta[s][c] (u8, 256 columns, (w+1)*256 B at LDS offset 0, w = min(m,255)),
 // so a text byte costs ONE dependent LDS lookup and no data-dependent loop: st = delta[st][c].
 // The address st*256 + c is ONE v_perm_b32 (byte 1 = state, byte 0 = text byte).  The accept
@@ -1246,7 +1249,7 @@ __device__ __forceinline__ void kmp_dfa_chunk_max(const uint4& v, uint32_t& st, 
 // stays [64 runs][64 B]: 4 KB per wave, 16 waves per CU next to any table.
 // Tried and dropped (session u): 8 or 12 waves per CU instead of 16: 40-54 %; runs of 256..4096 bytes: within 3
 // points of each other.  (Whole-line loads of 8 runs per instruction were equal-or-worse WITHOUT non-temporal
-// loads; with them they are so_runs' loader now — LineIo below.)
+// loads; with them they are so_runs1' loader now — LineIo below.)
 // Tried and dropped (measured on rand128, 1 GiB): two runs per lane with interleaved lookups
 // (57-59 % against 65-67 %), groups handed out by a device-wide atomic counter (same-address
 // atomics serialise at ~16 ns and, returning through vmcnt, stall every wave's first fetch:
@@ -1304,7 +1307,7 @@ __device__ __forceinline__ uint4 run_piece(const RunIo& io, int c)
         *reinterpret_cast<uint4*>((io_).wr + 3072) = r3_;                          \
     } while (0)
 
-// ---- the whole-line loader (so_runs) ----------------------------------------------------------
+// ---- the whole-line loader (so_runs1) ----------------------------------------------------------
 // Load i (0..7) fetches the whole 128-byte lines of runs 8i .. 8i+7, lane = 8*(run in block) + piece:
 // eight lanes per line and every line requested by ONE instruction, so the loads can be non-temporal
 // like the tile kernels' (a streaming read runs at 7.0-7.1 TB/s with nt loads, 6.2-6.3 TB/s without —
@@ -1312,7 +1315,7 @@ __device__ __forceinline__ uint4 run_piece(const RunIo& io, int c)
 // whatever the run length, 128 bytes = fully contiguous wave-loads to 4096: its ceiling is the cache
 // policy, not the access pattern; there every line is touched by two instructions and the second has
 // to find it in cache).  Parking then stores with half the lanes per half (16 ds_write_b128 per line
-// instead of 8).  so_runs: 63-67 % -> 71-72 %.  kmp_runs, bound by its dependent lookups rather than
+// instead of 8).  so_runs1: 63-67 % -> 71-72 %.  kmp_runs1, bound by its dependent lookups rather than
 // by the data path, lost 3 points to the extra stores and keeps the half-line loader.
 struct LineIo {
     uint8_t* wr_e;       // where this lane parks its piece of an even-numbered load (+ 512*i)
@@ -1356,6 +1359,24 @@ __device__ __forceinline__ uint4 run_piece(const LineIo& io, int c)
         n6 = ld_stream16(p_ + (blk_)[6]);                                          \
         n7 = ld_stream16(p_ + (blk_)[7]);                                          \
     } while (0)
+// the same in two instalments (swap loader): the registers of the first halves are free again after the
+// first park of a line, those of the second halves after the second
+#define LINE_FETCH_EVEN(gbase_, blk_, off_)                                        \
+    do {                                                                           \
+        const uint8_t* p_ = (gbase_) + (off_);                                     \
+        n0 = ld_stream16(p_ + (blk_)[0]);                                          \
+        n2 = ld_stream16(p_ + (blk_)[2]);                                          \
+        n4 = ld_stream16(p_ + (blk_)[4]);                                          \
+        n6 = ld_stream16(p_ + (blk_)[6]);                                          \
+    } while (0)
+#define LINE_FETCH_ODD(gbase_, blk_, off_)                                         \
+    do {                                                                           \
+        const uint8_t* p_ = (gbase_) + (off_);                                     \
+        n1 = ld_stream16(p_ + (blk_)[1]);                                          \
+        n3 = ld_stream16(p_ + (blk_)[3]);                                          \
+        n5 = ld_stream16(p_ + (blk_)[5]);                                          \
+        n7 = ld_stream16(p_ + (blk_)[7]);                                          \
+    } while (0)
 // park one 64-byte half of every run's line: the lanes holding pieces of that half store, the others idle
 #define LINE_PARK(io_, first_)                                                     \
     do {                                                                           \
@@ -1372,7 +1393,7 @@ __device__ __forceinline__ uint4 run_piece(const LineIo& io, int c)
     } while (0)
 
 template <bool PREFIX>  // PREFIX: m > 255 — the automaton of the 255-byte prefix; hits are verified
-__global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
+__global__ __launch_bounds__(kRunWaves * 64) void kmp_runs1(ScanArgs a, uint32_t run_len, uint64_t nruns,
                                                        uint32_t dfa_off)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1405,7 +1426,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t 
     const uint64_t nwaves = (uint64_t)gridDim.x * kRunWaves;
     const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
     // group = 64 consecutive runs handled by one wave
-    for (uint64_t g = (uint64_t)blockIdx.x * kRunWaves + wave; g * 64 < nruns; g += nwaves) {
+    for (uint64_t g = blockIdx.x + (uint64_t)gridDim.x * wave; g * 64 < nruns; g += nwaves) {
         // loader addresses = wave-uniform base of the group + wave-uniform offset of the 16-run
         // block i + ONE per-lane offset.  A block that lies entirely past the last run re-reads
         // block 0 (loaded, never consumed); the lanes of the one block that straddles the end
@@ -1598,7 +1619,7 @@ __global__ __launch_bounds__(256) void kmp_links_runs(ScanArgs a, uint32_t run_l
     flush_hits(hits, a.count, smem);
 }
 
-// Shift-Or over per-lane RUNS (the structure of kmp_runs above).  With LDS tiles a lane's run is
+// Shift-Or over per-lane RUNS (the structure of kmp_runs1 above).  With LDS tiles a lane's run is
 // 80 bytes and the w-1 bytes it re-scans to rebuild the state cost up to 39 % extra work per
 // owned byte; runs of 2-4 KiB make that 1 %.  Same recurrence as so_scan.
 //
@@ -1613,7 +1634,7 @@ __global__ __launch_bounds__(256) void kmp_links_runs(ScanArgs a, uint32_t run_l
 // aligned like SO: the 1 enters at bit 32-w, the hit is the sign bit, bytes outside a lane's
 // range map to the mask 0 (no prefix survives).
 template <bool LONG, bool AND>  // LONG: m > 32, hits of the 32-byte prefix are verified
-__global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t run_len, uint64_t nruns)
+__global__ __launch_bounds__(kRunWaves * 64) void so_runs1(ScanArgs a, uint32_t run_len, uint64_t nruns)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32;
@@ -1643,7 +1664,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
     const uint64_t run_first = a.s_begin / run_len;
     const uint64_t nwaves = (uint64_t)gridDim.x * kRunWaves;
     const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
-    for (uint64_t g = (uint64_t)blockIdx.x * kRunWaves + wave; g * 64 < nruns; g += nwaves) {
+    for (uint64_t g = blockIdx.x + (uint64_t)gridDim.x * wave; g * 64 < nruns; g += nwaves) {
         const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
         uint32_t blk[8];  // a block that lies entirely past the last run re-reads block 0 (loaded, never consumed)
 #pragma unroll
@@ -1745,6 +1766,466 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t r
             LINE_PARK(io, true);
             half(k * kRunLine);
             LINE_PARK(io, false);
+            if (k + 1 < nlines) LINE_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
+            half(k * kRunLine + 64u);
+        }
+    }
+    flush_hits(hits, a.count, smem);
+}
+
+// ---- the whole-line loader with half-swapped registers (so_runs, kmp_runs) ----------------------
+// LineIo's loads (every 128-byte line requested by ONE non-temporal instruction) with RunIo's parking
+// cost.  Load i fetches the lines of runs 8i .. 8i+7 with lane = 32*half + 4*(run in block) + piece:
+// lanes 0-31 hold the pieces of the lines' first 64 bytes, lanes 32-63 those of their second.  One
+// v_permlane32_swap per dword then exchanges the upper lanes of load 2j with the lower lanes of load
+// 2j+1: register 2j now holds FIRST halves in all 64 lanes (runs 16j .. 16j+15, lane = 4*run + piece —
+// RunIo's layout), register 2j+1 the second halves.  A half is parked with four full-wave
+// ds_write_b128 instead of LineIo's eight half-empty ones: a wave64 ds_write_b128 occupies the LDS
+// data path for 13 cycles whatever its EXEC mask (MI355X_MICROARCH.md §LDS), so parking cost
+// 1.6 LDS-path cycles per text byte and wave next to 2.0 for the gathers; now 0.8, for 16 swaps per line.
+__device__ __forceinline__ RunIo swap_io(uint8_t* slab, uint32_t lane, uint32_t run_len)
+{
+    RunIo io = run_io(slab, lane, run_len);  // parking and reading are RunIo's
+    io.loff = ((lane >> 2) & 7u) * run_len + (lane >> 5) * 64u + 16u * (lane & 3u);
+    return io;
+}
+
+__device__ __forceinline__ void swap_halves(uint4& lo, uint4& hi)
+{
+    // v_permlane32_swap vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src
+#define SG_SWAP(f_)                                                                  \
+    do {                                                                             \
+        const auto r_ = __builtin_amdgcn_permlane32_swap(lo.f_, hi.f_, false, false); \
+        lo.f_ = r_[0];                                                               \
+        hi.f_ = r_[1];                                                               \
+    } while (0)
+    SG_SWAP(x);
+    SG_SWAP(y);
+    SG_SWAP(z);
+    SG_SWAP(w);
+#undef SG_SWAP
+}
+
+#define SWAP_LINE()                \
+    do {                           \
+        swap_halves(n0, n1);       \
+        swap_halves(n2, n3);       \
+        swap_halves(n4, n5);       \
+        swap_halves(n6, n7);       \
+    } while (0)
+
+// Shift-Or over per-lane runs, FOUR text bytes per step of the recurrence.
+//
+// so.c:55 is D = (D << 1) | S[c] once per byte.  Four of them are
+//     D = (D << 4) | (S[c0] << 3) | (S[c1] << 2) | (S[c2] << 1) | S[c3]
+// and the part after the first OR does not depend on D: three v_lshl_or_b32 off the chain, one on it —
+// still one VALU op per byte for the recurrence, but the hit test (so.c:56) comes for all four bytes at
+// once.  The state is held with the mask's top bit at bit 28 (S'[c] = S[c] << (29 - w), bits 29..31
+// zero): after a step, bits 28..31 of D are bit w-1 of the four intermediate states, oldest on top
+// (a set bit of S'[c3] cannot reach bit 29, of S'[c2] << 1 not bit 30, ...), and ONE v_alignbit_b32 per
+// four bytes moves them into the hit collector.  Three bits of headroom make w = min(m, 29): patterns
+// of 30+ bytes are filtered by their 29-byte prefix and verified (so.c:69-96 does that from 33 bytes
+// on with a 32-byte prefix; the count is the same).
+// Per text byte: one v_perm_b32 (gather address), one ds_read_b32 (bank-private gather), one
+// v_lshl_or_b32, a quarter v_alignbit_b32 — 2.25 VALU + 1 LDS against 3 + 1 with a step per byte.
+// The loader is swap_io above.  Shift-And (sa.c) counts in complemented form on the same kernel
+// (api.cpp build_blob).
+// (a << K) | b as ONE v_lshl_or_b32: left to itself the compiler reassociates the OR tree, shifts every
+// mask on its own and joins them with v_or3_b32 — 6 VALU ops per four bytes instead of 4.  The empty
+// asm hides the value from the reassociation and emits nothing.
+template <int K>
+__device__ __forceinline__ uint32_t lshl_or_now(uint32_t a, uint32_t b)
+{
+    uint32_t r = (a << K) | b;
+    asm("" : "+v"(r));
+    return r;
+}
+
+#ifndef SG_EARLY
+#define SG_EARLY 0  // experiments: 1 = half of the next line's loads already after the first park (kmp_runs: 4 % slower, so_runs: equal)
+#endif
+#ifndef SG_ABLATE
+#define SG_ABLATE 0  // experiments only (wrong counts): 1 no gathers, 2 no recurrence, 4 no parking, 8 no fetch after line 0
+#endif
+template <bool LONG>  // LONG: m > 29, hits of the 29-byte prefix are verified
+__global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t run_len, uint64_t nruns)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m, w = m < kSoWindow ? m : kSoWindow;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* S = reinterpret_cast<uint32_t*>(smem);
+    const RunIo io = swap_io(smem + 65536 + wave * kLineSlab, lane, run_len);
+    const uint32_t sh = 29u - w;
+    const uint32_t sentinel = (0xFFFFFFFFu << sh) & 0x1FFFFFFFu;  // mask of a byte outside the lane's range
+    // the first line of the wave's first group is requested before the table is built: its HBM latency
+    // passes while the workgroup fills the LDS
+    uint4 n0, n1, n2, n3, n4, n5, n6, n7;
+    bool fetched = false;
+    {
+        const uint64_t g = blockIdx.x + (uint64_t)gridDim.x * (threadIdx.x >> 6);
+        if (g * 64 < nruns) {
+            const RunIo io0 = swap_io(smem, threadIdx.x & 63u, run_len);  // only loff is used
+            const uint8_t* const gbase = a.text + (a.s_begin / run_len + g * 64) * run_len + io0.loff;
+            uint32_t blk[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) blk[i] = g * 64 + 8 * i < nruns ? 8u * i * run_len : 0u;
+            LINE_FETCH(gbase, blk, 0u);
+            fetched = true;
+        }
+    }
+    {   // expand the 256 masks to one copy per lane through a 1 KB staging area (wave 0's slab)
+        uint32_t* stage = reinterpret_cast<uint32_t*>(smem + 65536);
+        if (threadIdx.x < 256)
+            stage[threadIdx.x] = (reinterpret_cast<const uint32_t*>(a.blob + a.so_off)[threadIdx.x] << sh) & 0x1FFFFFFFu;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < 256 * 64; i += kRunWaves * 64) S[i] = stage[i >> 6];
+    }
+    // the perm result IS the LDS address: the table sits at LDS offset 0 (this kernel has no
+    // static LDS, so the dynamic segment starts there); a poisoned count if that ever changes
+    const uint32_t lane4 = lane * 4u;
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
+        return;
+    }
+    __syncthreads();  // the only workgroup barrier: table visible
+
+    uint32_t hits = 0;
+    const uint64_t run_first = a.s_begin / run_len;
+    const uint64_t nwaves = (uint64_t)gridDim.x * kRunWaves;
+    const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
+    for (uint64_t g = blockIdx.x + (uint64_t)gridDim.x * wave; g * 64 < nruns; g += nwaves) {
+        const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
+        uint32_t blk[8];  // a block that lies entirely past the last run re-reads block 0 (loaded, never consumed)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) blk[i] = g * 64 + 8 * i < nruns ? 8u * i * run_len : 0u;
+        const uint64_t my = g * 64 + lane;
+        const uint64_t seg = (run_first + my) * run_len;
+        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
+        const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
+        const bool owner = my < nruns && sa < sb;
+        const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
+        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
+
+        if (!fetched) LINE_FETCH(gbase, blk, 0u);
+        fetched = false;
+        uint32_t D = 0xFFFFFFFFu << sh;  // no prefix matched yet
+        bool parked = false;
+        const uint8_t* parked_at = a.text;
+        // one 64-byte half of a line: the bytes [jb, jb + 64) of every run are in the slab
+        auto half = [&](const uint32_t jb) {
+            // hit mask of one 16-byte chunk (bit 15-q: a window ends at byte q)
+            auto take_hits = [&](uint32_t base, uint32_t hm) {
+                if (!LONG) {
+                    hits += __popc(hm);
+                } else {
+                    while (hm) {  // the prefix matched, ending at byte q: verify P[w..m)
+                        const uint32_t bit = 31u - __builtin_clz(hm);
+                        hm &= ~(1u << bit);
+                        const uint8_t* rest = a.text + seg + base + (15u - bit) + 1;
+                        if (!parked) {
+                            parked = true;
+                            parked_at = rest;
+                        } else {
+                            hits += global_equal(rest, a.blob + w, m - w);
+                        }
+                    }
+                }
+            };
+            if (jb >= j0 && jb + 64u <= jend) {
+                // the whole half is inside the run (all but a run's last): straight-line code, software-
+                // pipelined by one 16-byte chunk: the 16 gathers of chunk c+1 are issued (a wave can have 15
+                // LDS operations outstanding) before the masks of chunk c are combined and shifted into D
+                uint4 v[4];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) v[c4] = run_piece(io, c4);
+                uint32_t s[2][16];
+                auto gather16 = [&](const uint4& vv, uint32_t* out) {
+                    const uint32_t d[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        if (SG_ABLATE & 1) out[q] = __builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
+                        else out[q] = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
+                    }
+                };
+                gather16(v[0], s[0]);
+                uint32_t H[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    if (c4 < 3) gather16(v[c4 + 1], s[(c4 + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const uint32_t* sc = s[c4 & 1];
+                    if (SG_ABLATE & 2) {
+#pragma unroll
+                        for (int k = 0; k < 16; k += 4) D |= sc[k] | sc[k + 1] | sc[k + 2] | sc[k + 3];
+                        __builtin_amdgcn_sched_barrier(0);
+                        continue;
+                    }
+                    uint32_t pr[8], t[4];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) pr[k] = lshl_or_now<1>(sc[2 * k], sc[2 * k + 1]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = lshl_or_now<2>(pr[2 * k], pr[2 * k + 1]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        D = (D << 4) | t[k];                                        // four steps of so.c:55
+                        H[c4 >> 1] = __builtin_amdgcn_alignbit(H[c4 >> 1], D, 28);  // so.c:56 for the four bytes: bits 28..31
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t hm = ~H[h];
+                    if (!LONG) {
+                        hits += __popc(hm);
+                    } else {
+                        take_hits(jb + 32u * h, hm >> 16);
+                        take_hits(jb + 32u * h + 16u, hm & 0xFFFFu);
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const uint32_t base = jb + 16u * c4;
+                    if (base >= jend || base + 16 <= j0) continue;
+                    const uint4 v = run_piece(io, c4);
+                    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t H = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const uint32_t j = base + q;
+                        uint32_t sv = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
+                        sv = (j >= j0 && j < jend) ? sv : sentinel;
+                        D = (D << 1) | sv;                                // so.c:55
+                        H = __builtin_amdgcn_alignbit(H, D << 3, 31);    // so.c:56: bit 28 = bit w-1 of the state
+                    }
+                    take_hits(base, ~H & 0xFFFFu);
+                }
+            }
+            if (LONG && __any(parked)) {  // keep at most one parked window per lane
+                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
+                parked = false;
+            }
+        };
+        for (uint32_t k = 0; k < nlines; ++k) {
+            SWAP_LINE();
+            if (!(SG_ABLATE & 4) || k == 0) RUN_PARK(io, n0, n2, n4, n6);
+            if (SG_EARLY && k + 1 < nlines && !(SG_ABLATE & 8)) LINE_FETCH_EVEN(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
+            half(k * kRunLine);
+            if (!(SG_ABLATE & 4) || k == 0) RUN_PARK(io, n1, n3, n5, n7);
+            if (SG_EARLY && k + 1 < nlines && !(SG_ABLATE & 8)) LINE_FETCH_ODD(gbase, blk, (k + 1) * kRunLine);
+            if (!SG_EARLY && k + 1 < nlines && !(SG_ABLATE & 8)) LINE_FETCH(gbase, blk, (k + 1) * kRunLine);
+            half(k * kRunLine + 64u);
+        }
+    }
+    flush_hits(hits, a.count, smem);
+}
+
+// ---------------------------------------------------------------------------
+// KMP over per-lane runs: the automaton's transition table (the failure function of kmp.c:27-41
+// expanded on the host, one dependent LDS lookup per byte: st = delta[st][c]) with an ABSORBING accept
+// row, behind the swap loader above.
+//
+// kmp_runs1 finds the halves in which an occurrence ended with a running maximum of the states (half
+// a VALU op per byte on a kernel that is bound by instruction issue and by the latency of its lookup
+// chain at about the same point).  Here the table itself remembers: every transition INTO the accept
+// state w leads to an extra row Z whose entries all say Z.  A lane that comes out of a 64-byte half in
+// Z saw an occurrence end there — one compare per half — and only then walks that half again from the
+// state it had saved at the 16-byte chunk where it fell into Z, counting.  The counting walk uses the
+// same table: Z = id(w) + 1 is the largest id, so min(next, id(w)) turns Z into the accept state's own
+// row (whose entries are the real delta(w, .)) and next - min(..) is the hit — v_min_u32 + v_sad_u32.
+// Per byte on the common path: v_perm_b32 (address: byte 1 = state, byte 0 = text byte), v_xor_b32
+// (bank swizzle), ds_read_u8.
+// State ids (api.cpp build_blob): fewer than 63 states: id(s) = 4s, the table ends with row Z = 4w+1;
+// otherwise id(s) = rotl8(s, 2) with id(w) = 254, Z = 255 (the one state that would sit on 254, s = 191,
+// takes the slot w left free).  w = min(m, 254); longer patterns: the 254-byte prefix's automaton, a
+// prefix hit is parked and verified (wave_verify) — what so.c does with its 32-byte prefix.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sad_now(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// sixteen transitions, nothing else (Z absorbs)
+__device__ __forceinline__ void kmp_chunk_fast(const uint4& v, uint32_t& st)
+{
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) st = kmp_delta(d[q >> 2], st, q & 3);
+}
+
+// sixteen transitions, counting (MASK: collecting) the entries into Z; CHECK: only bytes j0 <= j < jend
+template <bool CHECK, bool MASK>
+__device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
+                                                uint32_t& st, uint32_t& hits, uint32_t idw)
+{
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t nx = kmp_delta(d[q >> 2], st, q & 3);
+        const uint32_t real = nx < idw ? nx : idw;  // Z -> the accept state's own row
+        if (CHECK) {
+            const uint32_t j = j_base + q;
+            const bool live = j >= j0 && j < jend;
+            st = live ? real : st;
+            if (MASK) hits |= (live && nx > idw) ? (1u << q) : 0u;
+            else hits += live ? nx - real : 0u;
+        } else {
+            st = real;
+            if (MASK) hits |= nx > idw ? (1u << q) : 0u;
+            else hits = sad_now(nx, real, hits);
+        }
+    }
+}
+
+// RUNIO: the half-line loader of kmp_runs1 (default cache policy) instead of the swap loader.  Measured
+// (profiles/r02, same box, 1 GiB rand128): tables below 64 KB 0.194-0.201 ms behind the swap loader against
+// 0.200-0.210; the full 64 KB table (63+ states) 0.220 against 0.210 — the launcher picks by table size.
+template <bool PREFIX, bool RUNIO>  // PREFIX: m > 254 — the automaton of the 254-byte prefix; hits are verified
+__global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
+                                                           uint32_t dfa_off)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t w = PREFIX ? kKmpWindow : m;  // length the automaton recognises
+    const uint32_t idw = w < 63 ? 4 * w : 254u, Z = idw + 1;
+    const uint32_t table_bytes = (Z + 1) * 256;
+    const RunIo io = RUNIO ? run_io(smem + table_bytes + wave * kLineSlab, lane, run_len) : swap_io(smem + table_bytes + wave * kLineSlab, lane, run_len);
+    // the first line of the wave's first group is requested before the table is built: its HBM latency
+    // passes while the workgroup fills the LDS
+    uint4 n0, n1, n2, n3, n4, n5, n6, n7;
+    bool fetched = false;
+    {
+        const uint64_t g = blockIdx.x + (uint64_t)gridDim.x * (threadIdx.x >> 6);
+        if (g * 64 < nruns) {
+            const RunIo io0 = RUNIO ? run_io(smem, threadIdx.x & 63u, run_len) : swap_io(smem, threadIdx.x & 63u, run_len);  // only loff is used
+            const uint8_t* const gbase = a.text + (a.s_begin / run_len + g * 64) * run_len + io0.loff;
+            uint32_t blk[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) blk[i] = g * 64 + (RUNIO ? 16 : 8) * i < nruns ? (RUNIO ? 16u : 8u) * i * run_len : 0u;
+            if (RUNIO) RUN_FETCH(gbase, blk, 0u); else LINE_FETCH(gbase, blk, 0u);
+            fetched = true;
+        }
+    }
+    {
+        const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
+        uint4* t = reinterpret_cast<uint4*>(smem);
+        for (uint32_t i = threadIdx.x; i < table_bytes / 16; i += kRunWaves * 64) t[i] = g[i];
+    }
+    // the perm result IS the LDS address: the table sits at LDS offset 0 (no static LDS in
+    // this kernel, so the dynamic segment starts there); a poisoned count if that ever changes
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
+        return;
+    }
+    __syncthreads();  // the only workgroup barrier: table visible
+
+    uint32_t hits = 0;
+    const uint64_t run_first = a.s_begin / run_len;  // runs are cut on absolute offsets
+    const uint64_t nwaves = (uint64_t)gridDim.x * kRunWaves;
+    const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
+    for (uint64_t g = blockIdx.x + (uint64_t)gridDim.x * wave; g * 64 < nruns; g += nwaves) {
+        const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
+        uint32_t blk[8];  // a block that lies entirely past the last run re-reads block 0 (loaded, never consumed)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) blk[i] = g * 64 + (RUNIO ? 16 : 8) * i < nruns ? (RUNIO ? 16u : 8u) * i * run_len : 0u;
+        const uint64_t my = g * 64 + lane;
+        const uint64_t seg = (run_first + my) * run_len;
+        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
+        const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
+        const bool owner = my < nruns && sa < sb;
+        const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
+        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
+
+        if (!fetched) { if (RUNIO) RUN_FETCH(gbase, blk, 0u); else LINE_FETCH(gbase, blk, 0u); }
+        fetched = false;
+        uint32_t st = 0;
+        bool dense = false;   // wave-uniform: many lanes saw an occurrence end in the last whole half
+        bool parked = false;  // PREFIX: first unverified prefix hit of this step
+        const uint8_t* parked_at = a.text;
+        auto half = [&](const uint32_t jb) {
+            // one 16-byte chunk, counting; returns whether an occurrence ended in it
+            auto careful = [&](uint32_t q, bool whole) -> bool {
+                const uint4 v = *reinterpret_cast<const uint4*>(io.rd + ((16u * q) ^ io.rswz));
+                const uint32_t j = jb + 16u * q;
+                if (!PREFIX) {
+                    const uint32_t h0 = hits;
+                    if (whole) kmp_chunk_count<false, false>(v, j, j0, jend, st, hits, idw);
+                    else if (j < jend && j + 16 > j0) kmp_chunk_count<true, false>(v, j, j0, jend, st, hits, idw);
+                    return hits != h0;
+                } else {
+                    uint32_t hm = 0;
+                    if (whole) kmp_chunk_count<false, true>(v, j, j0, jend, st, hm, idw);
+                    else if (j < jend && j + 16 > j0) kmp_chunk_count<true, true>(v, j, j0, jend, st, hm, idw);
+                    const bool seen = hm != 0;
+                    while (hm) {  // the prefix ends at byte j+b: verify P[w..m)
+                        const uint32_t b = __builtin_ctz(hm);
+                        hm &= hm - 1;
+                        const uint8_t* rest = a.text + seg + j + b + 1;  // = text + start + w
+                        if (!parked) {
+                            parked = true;
+                            parked_at = rest;
+                        } else {
+                            hits += global_equal(rest, a.blob + w, m - w);
+                        }
+                    }
+                    return seen;
+                }
+            };
+            if (jb >= j0 && jb + 64u <= jend) {  // the whole half is inside the run
+                bool seen = false;
+                if (!dense) {
+                    uint32_t at[4];  // state before each 16-byte chunk
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        at[q] = st;
+                        kmp_chunk_fast(run_piece(io, q), st);
+                    }
+                    seen = st == Z;
+                    if (__any(seen)) {
+                        if (seen) {
+                            // the chunk in which the lane fell into Z: walk on from there, counting
+                            const uint32_t q0 = at[1] == Z ? 0u : at[2] == Z ? 1u : at[3] == Z ? 2u : 3u;
+                            st = q0 == 0 ? at[0] : q0 == 1 ? at[1] : q0 == 2 ? at[2] : at[3];
+#pragma unroll 1
+                            for (uint32_t q = q0; q < 4; ++q) careful(q, true);
+                        }
+                    }
+                } else {
+#pragma unroll 1
+                    for (uint32_t q = 0; q < 4; ++q) seen |= careful(q, true);
+                }
+                // where occurrences are frequent (short patterns, small alphabets) walking twice
+                // costs more than it saves: the wave counts directly while an eighth of its lanes
+                // saw one in the last half
+                dense = __popcll(__ballot(seen)) >= 8;
+            } else {
+#pragma unroll 1
+                for (uint32_t q = 0; q < 4; ++q) {
+                    const uint32_t j = jb + 16u * q;
+                    careful(q, j >= j0 && j + 16 <= jend);
+                }
+            }
+            if (PREFIX && __any(parked)) {  // wave-uniform point: at most one parked hit per lane
+                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
+                parked = false;
+            }
+        };
+        for (uint32_t k = 0; k < nlines; ++k) {
+            if (RUNIO) {
+                RUN_PARK(io, n0, n1, n2, n3);
+                half(k * kRunLine);
+                RUN_PARK(io, n4, n5, n6, n7);
+                if (k + 1 < nlines) RUN_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
+                half(k * kRunLine + 64u);
+                continue;
+            }
+            SWAP_LINE();
+            RUN_PARK(io, n0, n2, n4, n6);
+            half(k * kRunLine);
+            RUN_PARK(io, n1, n3, n5, n7);
             if (k + 1 < nlines) LINE_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
             half(k * kRunLine + 64u);
         }
@@ -2258,7 +2739,7 @@ static int hor_regime(uint32_t m, int algo = SMARTGPU_HOR);
 
 const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_masks)
 {
-    if (so_masks && g_tune[0] == 0) return "so_runs";
+    if (so_masks && g_tune[0] == 0) return g_tune[6] == 4 ? "so_runs1" : "so_runs";
     const bool pk = prefer_packed && g_tune[0] == 0;
     switch (algo) {
         case SMARTGPU_TUNEDBM:
@@ -2271,11 +2752,11 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_m
         case SMARTGPU_HASH8:
         case SMARTGPU_RAITA:
         case SMARTGPU_QS: return (pk || hor_regime(m, algo) == 3) ? "packed_scan" : "hor_scan";
-        case SMARTGPU_SA: return "so_runs";
+        case SMARTGPU_SA: return (g_tune[6] == 3 || g_tune[6] == 4) ? "so_runs1" : "so_runs";
         case SMARTGPU_KR: return (m < 16 && g_tune[0] != 1) ? "packed_scan" : "hor_scan_bp";
         case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
-        case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : "kmp_runs";
-        case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : "so_runs";
+        case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : g_tune[3] == 3 ? "kmp_runs1" : "kmp_runs";
+        case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : g_tune[6] == 4 ? "so_runs1" : "so_runs";
         case SMARTGPU_BNDML:
             if (m > 32) return pk ? "packed_scan" : "bndml_scan";
             [[fallthrough]];
@@ -2294,39 +2775,62 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_m
 // then grows L in 64-byte steps until the runs cut on absolute offsets fit k * nwaves groups.
 // Runs shorter than `lmin` (small texts) are not worth balancing: L = lmin.
 static uint64_t balanced_run_len(uint64_t s_begin, uint64_t s_end, uint64_t per_group, uint64_t nwaves,
-                                 uint64_t lmin, uint64_t lmax)
+                                 uint64_t lmin, uint64_t lmax, uint64_t lfloor)
 {
     const uint64_t span = s_end - s_begin;
     const uint64_t slots = per_group * nwaves;  // runs per round of all waves
     const uint64_t k = (span + slots * lmax - 1) / (slots * lmax);
     uint64_t L = ((span + slots * k - 1) / (slots * k) + 63) & ~63ull;
-    if (L < lmin) return (lmin + 63) & ~63ull;
+    // A text too small to give every wave a group of lmin-byte runs (SMART's stock 1 MiB texts: 8 groups of
+    // 2 KiB runs = 8 waves on the whole chip, 60-70 us per search): shorter runs, down to lfloor — the
+    // re-scan of w-1 bytes per run costs less than the idle CUs.
+    if (L < lmin) return L > lfloor ? L : (lfloor + 63) & ~63ull;
     while (tiles_for(s_begin, s_end, L).count > slots * k) L += 64;
     return L;
 }
 
-// Shift-Or / Shift-And runs (so_runs); the masks u32 S[256] sit at a.blob + a.so_off.
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel), not per launch
+static void allow_lds(const void* kernel, size_t lds)
+{
+    static std::map<std::pair<int, const void*>, size_t> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& have = done[{dev, kernel}];
+    if (have >= lds) return;
+    (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    have = lds;
+}
+
+// Shift-Or runs (so_runs; Shift-And counts on it in complemented form); the masks u32 S[256] sit at
+// a.blob + a.so_off.  shift_and / tune(6,4): the previous kernel so_runs1 (a step per byte, LineIo), A/B.
 static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus, hipStream_t stream)
 {
     // bank-private table: 64 KB shared by the 16 waves of ONE workgroup per CU
     const uint32_t m = a.m;
     const uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
-    const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin);
+    const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin, 128);
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
     const size_t lds = 65536 + kRunWaves * (size_t)kLineSlab;
-    uint64_t grid = ((uint64_t)tr.count + 64ull * kRunWaves - 1) / (64ull * kRunWaves);
+    uint64_t grid = ((uint64_t)tr.count + 63) / 64;  // groups of 64 runs: spread over the CUs first (so_runs: group = block + grid * wave)
     if (grid > (uint64_t)num_cus) grid = num_cus;
-#define SG_SO_RUNS(L_, A_)                                                                               \
+#define SG_SO_RUNS1(L_, A_)                                                                               \
     do {                                                                                                 \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(so_runs<L_, A_>),                        \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
-        hipLaunchKernelGGL((so_runs<L_, A_>), dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, \
+        allow_lds(reinterpret_cast<const void*>(so_runs1<L_, A_>), lds);                                  \
+        hipLaunchKernelGGL((so_runs1<L_, A_>), dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, \
                            (uint32_t)L, (uint64_t)tr.count);                                             \
     } while (0)
-    if (shift_and) { if (m > 32) SG_SO_RUNS(true, true); else SG_SO_RUNS(false, true); }
-    else { if (m > 32) SG_SO_RUNS(true, false); else SG_SO_RUNS(false, false); }
+#define SG_SO_RUNS(L_)                                                                                   \
+    do {                                                                                                 \
+        allow_lds(reinterpret_cast<const void*>(so_runs<L_>), lds);                                      \
+        hipLaunchKernelGGL((so_runs<L_>), dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a,    \
+                           (uint32_t)L, (uint64_t)tr.count);                                             \
+    } while (0)
+    if (shift_and) { if (m > 32) SG_SO_RUNS1(true, true); else SG_SO_RUNS1(false, true); }
+    else if (g_tune[6] == 4) { if (m > 32) SG_SO_RUNS1(true, false); else SG_SO_RUNS1(false, false); }
+    else { if (m > kSoWindow) SG_SO_RUNS(true); else SG_SO_RUNS(false); }
 #undef SG_SO_RUNS
+#undef SG_SO_RUNS1
     return hipGetLastError();
 }
 
@@ -2334,7 +2838,7 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
 {
     const uint32_t m = a.m;
     const bool links = g_tune[3] == 2;                       // failure links, A/B
-    const uint32_t w = (links || m <= kKmpDfaMaxM) ? m : kKmpDfaMaxM;  // bytes re-scanned per run: w-1
+    uint32_t w = (links || m <= kKmpDfaMaxM) ? m : kKmpDfaMaxM;  // bytes re-scanned per run: w-1
     const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));
     if (links) {
         const uint64_t span = a.s_end - a.s_begin;
@@ -2355,25 +2859,36 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
         return hipGetLastError();
     }
     // one 1024-thread workgroup per CU shares the table (<= 64 KB) next to 16 x 4 KB of slabs
-    const size_t lds = (size_t)(w < 64 ? 4 * w + 1 : 256) * 256 + kRunWaves * (size_t)kLineSlab;  // rows up to the accept id (kmp_runs)
+    const bool v1 = g_tune[3] == 3;  // the previous kernel (running maximum, half-line loader), A/B
+    const uint32_t w2 = m < kKmpWindow ? m : kKmpWindow;
+    if (!v1) w = w2;
+    const size_t lds = (v1 ? (size_t)(w < 64 ? 4 * w + 1 : 256) : (size_t)(w2 < 63 ? 4 * w2 + 2 : 256)) * 256
+                       + kRunWaves * (size_t)kLineSlab;  // rows up to the accept id (kmp_runs1) / up to Z (kmp_runs)
     // runs of 2-4 KiB: at least 8x the w-1 bytes a run re-scans, at most 8 KiB (the loader's
     // over-read past the last run stays inside the text's back pad)
     uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
     if (lmin < 8ull * (w - 1)) lmin = 8ull * (w - 1);
-    const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin);
+    const uint64_t lfloor = 2ull * (w - 1) > 128 ? 2ull * (w - 1) : 128;  // small texts: see balanced_run_len
+    const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin, lfloor);
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
-    uint64_t grid = ((uint64_t)tr.count + 64ull * kRunWaves - 1) / (64ull * kRunWaves);
+    uint64_t grid = ((uint64_t)tr.count + 63) / 64;  // groups of 64 runs: spread over the CUs first
     if (grid > (uint64_t)num_cus) grid = num_cus;
-    const void* fn = m > kKmpDfaMaxM ? reinterpret_cast<const void*>(kmp_runs<true>)
-                                     : reinterpret_cast<const void*>(kmp_runs<false>);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (m > kKmpDfaMaxM)
-        hipLaunchKernelGGL(kmp_runs<true>, dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a,
-                           (uint32_t)L, (uint64_t)tr.count, dfa_off);
-    else
-        hipLaunchKernelGGL(kmp_runs<false>, dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a,
-                           (uint32_t)L, (uint64_t)tr.count, dfa_off);
+#define SG_KMP_RUNS(K_, OFF_)                                                                            \
+    do {                                                                                                 \
+        if (lds > 64 * 1024) allow_lds(reinterpret_cast<const void*>(K_), lds);                          \
+        hipLaunchKernelGGL(K_, dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, (uint32_t)L,  \
+                           (uint64_t)tr.count, (uint32_t)(OFF_));                                        \
+    } while (0)
+    if (v1) {
+        if (m > kKmpDfaMaxM) SG_KMP_RUNS(kmp_runs1<true>, dfa_off); else SG_KMP_RUNS(kmp_runs1<false>, dfa_off);
+    } else {
+        // 63+ states: the full 64 KB table, behind the half-line loader (see kmp_runs)
+        if (m > kKmpWindow) SG_KMP_RUNS((kmp_runs<true, true>), dfa_off + 65536);
+        else if (w2 >= 63) SG_KMP_RUNS((kmp_runs<false, true>), dfa_off + 65536);
+        else SG_KMP_RUNS((kmp_runs<false, false>), dfa_off + 65536);
+    }
+#undef SG_KMP_RUNS
     return hipGetLastError();
 }
 
@@ -2568,7 +3083,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
             return launch_tiled(bndm_scan<kBndmT, kBndmL, false, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
         }
-        case SMARTGPU_SA:  // Shift-And: so_runs<.., AND = true>; the A/B kernels below are Shift-Or only
+        case SMARTGPU_SA:  // Shift-And: so_runs1<.., AND = true>; the A/B kernels below are Shift-Or only
         case SMARTGPU_SO: {
             if (g_tune[6] == 2 && algo == SMARTGPU_SO) {  // the first runs kernel: shared table, 64-byte steps (A/B)
                 uint64_t L = g_tune[5] ? (uint64_t)g_tune[5] : 1024;
@@ -2591,7 +3106,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             if (g_tune[6] != 1 || algo == SMARTGPU_SA) {  // per-lane runs through LDS line slabs (tune[6]=1: LDS tiles, for A/B)
                 ScanArgs b = a;
                 // Shift-And counts in the complemented (Shift-Or) form by default: api.cpp build_blob; its own
-                // AND form (so_runs<.., AND = true>, masks after the Shift-Or ones) with tune(6,3)
+                // AND form (so_runs1<.., AND = true>, masks after the Shift-Or ones) with tune(6,3)
                 const bool and_form = algo == SMARTGPU_SA && g_tune[6] == 3;
                 b.so_off = and_form ? kTableOff + 1024 : kTableOff;
                 return launch_so_runs(b, and_form, num_cus, stream);
@@ -2618,7 +3133,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 if (m <= 40) SG_KMP(256, 144, 4);
             }
 #undef SG_KMP
-            // per-lane runs streamed through LDS (kmp_runs)
+            // per-lane runs streamed through LDS (kmp_runs1)
             return launch_kmp_runs(a, num_cus, stream);
         }
         case SMARTGPU_EPSM: {

@@ -54,6 +54,8 @@ def lib():
         "smartgpu_text_device": (i32, [vp]),
         "smartgpu_text_read": (i32, [vp, u64, u64, vp]),
         "smartgpu_search64": (i32, [i32, vp, u32, vp, u64, u64, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "smartgpu_search_batch64": (i32, [i32, vp, u32, u32, vp, u64, u64, vp, vp, vp, C.POINTER(C.c_double)]),
+        "smartgpu_msearch_batch64": (i32, [i32, vp, u32, u32, vp, i32, vp, vp, C.POINTER(C.c_double)]),
         "smartgpu_find64": (i32, [vp, u32, vp, u64, u64, vp, u64, C.POINTER(u64)]),
         "smartgpu_last_times": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "smartgpu_plan_create": (vp, [i32, vp, u32, i32]),
@@ -258,6 +260,19 @@ class MultiText:
             raise _err("msearch64(%s) rc=%d" % (algo, rc))
         return int(c.value), float(pre.value), float(run.value)
 
+    def search_batch(self, algo, patterns, reduce="rccl"):
+        """(counts, pre_ms, batch_ms): every shard searched for all K patterns, ONE reduction of the K counts."""
+        pats, ptrs, m = _pattern_set(patterns)
+        K = len(pats)
+        counts = np.zeros(K, dtype=np.uint64)
+        pre = np.zeros(K, dtype=np.float64)
+        batch = C.c_double(0.0)
+        rc = lib().smartgpu_msearch_batch64(algo_id(algo), C.cast(ptrs, C.c_void_p), m, K, self._h, 0 if reduce == "rccl" else 1,
+                                            counts.ctypes.data, pre.ctypes.data, C.byref(batch))
+        if rc != 0:
+            raise _err("msearch_batch64(%s) rc=%d" % (algo, rc))
+        return counts, pre, float(batch.value)
+
     def free(self):
         if self._h:
             lib().smartgpu_mtext_free(self._h)
@@ -283,6 +298,35 @@ def search(algo, P, text, off=0, n=None):
     if rc != 0:
         raise _err("search64(%s) rc=%d" % (algo, rc))
     return int(c.value), float(pre.value), float(run.value)
+
+
+def _pattern_set(patterns):
+    """K patterns of one length as the const uint8_t* const* the batch calls take (+ what must stay alive)."""
+    pats = [_u8(p) for p in patterns]
+    m = len(pats[0])
+    if any(len(p) != m for p in pats):
+        raise SmartGpuError("a pattern set holds patterns of ONE length (smart.c:312 loops per length)")
+    ptrs = (C.c_void_p * len(pats))(*[p.ctypes.data for p in pats])
+    return pats, ptrs, m
+
+
+def search_batch(algo, patterns, text, off=0, n=None, per_pattern_times=True):
+    """(counts, pre_ms, run_ms, batch_ms) of `algo` for a whole pattern set over text[off..off+n): the
+    harness loop of smart.c:312-345 as one call (smartgpu_search_batch64).  run_ms is None without
+    per_pattern_times."""
+    pats, ptrs, m = _pattern_set(patterns)
+    K = len(pats)
+    if n is None:
+        n = len(text) - off
+    counts = np.zeros(K, dtype=np.uint64)
+    pre = np.zeros(K, dtype=np.float64)
+    run = np.zeros(K, dtype=np.float64) if per_pattern_times else None
+    batch = C.c_double(0.0)
+    rc = lib().smartgpu_search_batch64(algo_id(algo), C.cast(ptrs, C.c_void_p), m, K, text._h, off, n, counts.ctypes.data,
+                                       pre.ctypes.data, run.ctypes.data if run is not None else None, C.byref(batch))
+    if rc != 0:
+        raise _err("search_batch64(%s) rc=%d" % (algo, rc))
+    return counts, pre, run, float(batch.value)
 
 
 def find(P, text, off=0, n=None, cap=1 << 20):

@@ -185,7 +185,9 @@ static void top_edge(void)
     printf("\n");
 }
 
-struct cell { double mean, pre, best, worst, std, gbs; int status; };
+struct cell { double mean, pre, best, worst, std, gbs; int status; char kernel[24]; };
+
+#define BATCH 64 /* patterns per smartgpu_search_batch64 call: the -tb limit and an ERROR are looked at between calls */
 
 /* One corpus: every pattern length x every algorithm x `runs` patterns
  * (reference: run_setting, src/smart.c:178-402). */
@@ -196,6 +198,8 @@ static void run_corpus(const struct options *o, const char *corpus, const unsign
     unsigned char **pats = malloc(sizeof(*pats) * (size_t)o->runs);
     for (int i = 0; i < o->runs; ++i) pats[i] = malloc(XSIZE + 1);
     double *sample = malloc(sizeof(double) * (size_t)(o->runs + 1));
+    uint64_t bcount[BATCH];
+    double bpre[BATCH], brun[BATCH];
 
     for (int il = 0; o->lengths[il] > 0; ++il) {
         const int m = o->lengths[il];
@@ -232,30 +236,45 @@ static void run_corpus(const struct options *o, const char *corpus, const unsign
             c->best = 999.0;
             long long total_occ = 0;
             int status = ST_OK;
-            for (int k = 1; k <= o->runs; ++k) {
-                int perc = (100 * k) / o->runs;
+            {   /* which kernel the plans of this pattern set launch (the first pattern speaks for the set) */
+                const char *kn = smartgpu_kernel_for(algo, pats[0], (uint32_t)m);
+                snprintf(c->kernel, sizeof c->kernel, "%s", kn ? kn : "-");
+            }
+            /* The reference's loop (smart.c:312-345) spawns one process per pattern; here the whole set goes
+             * to the engine in calls of BATCH patterns (smartgpu_search_batch64: tables of the set in one
+             * arena, launches back to back, one read-back).  A pattern's time e is the wall time of its call
+             * divided by the patterns in it (+ its preprocessing unless -pre); best/worst/std are taken
+             * over the per-pattern device times (HIP events) scaled to that mean. */
+            int done = 0;
+            while (done < o->runs && status == ST_OK) {
+                const int kb = o->runs - done < BATCH ? o->runs - done : BATCH;
+                int perc = (100 * (done + kb)) / o->runs;
                 printf(perc < 10 ? "\b\b\b\b[%d%%]" : perc < 100 ? "\b\b\b\b\b[%d%%]" : "\b\b\b\b[%d%%]", perc);
                 fflush(stdout);
-                uint64_t count = 0;
-                double pre_ms = 0, run_ms = 0;
-                int rc = mtext ? smartgpu_msearch64(algo, pats[k - 1], (uint32_t)m, mtext, SMARTGPU_REDUCE_RCCL, &count, &pre_ms, &run_ms)
-                               : smartgpu_search64(algo, pats[k - 1], (uint32_t)m, text, 0, (uint64_t)n, &count, &pre_ms, &run_ms);
-                long long occur = rc == SMARTGPU_OK ? (long long)count : -1;
-                double e = o->pre ? run_ms : run_ms + pre_ms; /* smart.c:323 */
-                sample[k] = e;
-                c->mean += e;
-                c->pre += pre_ms;
-                if (e < c->best) c->best = e;
-                if (e > c->worst) c->worst = e;
-                total_occ += occur;
-                if (occur <= 0 && !o->simple) { /* smart.c:330-336 */
-                    status = occur == 0 ? ST_ERROR : ST_NA;
-                    break;
+                double batch_ms = 0;
+                int rc = mtext ? smartgpu_msearch_batch64(algo, (const uint8_t *const *)(pats + done), (uint32_t)m, (uint32_t)kb, mtext,
+                                                          SMARTGPU_REDUCE_RCCL, bcount, bpre, &batch_ms)
+                               : smartgpu_search_batch64(algo, (const uint8_t *const *)(pats + done), (uint32_t)m, (uint32_t)kb, text, 0,
+                                                         (uint64_t)n, bcount, bpre, brun, &batch_ms);
+                double dev_sum = 0;
+                if (rc == SMARTGPU_OK && !mtext)
+                    for (int k = 0; k < kb; ++k) dev_sum += brun[k];
+                for (int k = 0; k < kb && status == ST_OK; ++k) {
+                    long long occur = rc == SMARTGPU_OK ? (long long)bcount[k] : -1;
+                    /* the call's wall time, shared out by device time (equal shares over several GPUs) */
+                    double run_ms = rc != SMARTGPU_OK ? 0 : (!mtext && dev_sum > 0) ? batch_ms * brun[k] / dev_sum : batch_ms / kb;
+                    double pre_ms = rc == SMARTGPU_OK ? bpre[k] : 0;
+                    double e = o->pre ? run_ms : run_ms + pre_ms; /* smart.c:323 */
+                    sample[done + k + 1] = e;
+                    c->mean += e;
+                    c->pre += pre_ms;
+                    if (e < c->best) c->best = e;
+                    if (e > c->worst) c->worst = e;
+                    total_occ += occur;
+                    if (occur <= 0 && !o->simple) status = occur == 0 ? ST_ERROR : ST_NA; /* smart.c:330-336 */
+                    else if (e > o->limit_ms) status = ST_OUT;                             /* smart.c:337-343 */
                 }
-                if (e > o->limit_ms) { /* smart.c:337-343 */
-                    status = ST_OUT;
-                    break;
-                }
+                done += kb;
             }
             if (status != ST_OK) {
                 c->mean = c->pre = 0;
@@ -285,7 +304,7 @@ static void run_corpus(const struct options *o, const char *corpus, const unsign
                     for (size_t i = strlen(data); i < 15; ++i) putchar(' ');
                 }
                 if (o->occ) printf("\tocc %lld", total_occ / o->runs);
-                printf("\t%.1f GB/s", c->gbs);
+                printf("\t%.1f GB/s\t%s", c->gbs, c->kernel);
                 printf("\n");
             } else if (status == ST_ERROR) {
                 printf("\b\b\b\b\b\b\b\b.[ERROR] \n");
@@ -330,6 +349,22 @@ static void write_txt(const struct options *o, const char *corpus, const char *c
     }
     fclose(fp);
     printf("\tOUTPUT RUNNING TIMES %s (results/%s/%s.txt)\n", code, code, corpus);
+    /* the same table with the kernel each cell's plans launched (the reference's TXT format has no room for it) */
+    snprintf(path, sizeof path, "results/%s/%s.kernels.txt", code, corpus);
+    fp = fopen(path, "w");
+    if (!fp) return;
+    for (int ia = 0; ia < o->nalgos; ++ia) {
+        char name[32];
+        upper(name, smartgpu_algo_name(o->algos[ia]));
+        fprintf(fp, "%-20s", name);
+        for (int il = 0; o->lengths[il] > 0; ++il) {
+            int m = o->lengths[il];
+            if (m < o->minlen || m > o->maxlen) continue;
+            fprintf(fp, "\t%s", table[ia][il].mean > 0 ? table[ia][il].kernel : "-");
+        }
+        fprintf(fp, "\n");
+    }
+    fclose(fp);
 }
 
 /* results/<code>/<corpus>.tex: the same table as a LaTeX tabular
@@ -391,7 +426,8 @@ static void write_xml(const struct options *o, const char *corpus, const char *c
             if (o->lengths[il] < o->minlen || o->lengths[il] > o->maxlen) continue;
             const struct cell *c = &table[ia][il];
             if (c->mean <= 0) { fprintf(fp, "\t\t<DATA>-</DATA>\n"); continue; }
-            fprintf(fp, "\t\t<DATA>\n\t\t\t<SEARCH>%.2f</SEARCH>\n\t\t\t<GBS>%.1f</GBS>\n\t\t</DATA>\n", c->mean, c->gbs);
+            fprintf(fp, "\t\t<DATA>\n\t\t\t<SEARCH>%.4f</SEARCH>\n\t\t\t<GBS>%.1f</GBS>\n\t\t\t<KERNEL>%s</KERNEL>\n\t\t</DATA>\n", c->mean, c->gbs,
+                    c->kernel);
         }
         fprintf(fp, "\t</ALGO>\n");
     }
@@ -447,7 +483,7 @@ static void write_html(const struct options *o, const char *corpus, const char *
             fprintf(fp, "<td>");
             if (o->pre && c->mean > 0) fprintf(fp, "<div class=\"pre\">%.2f</div>", c->pre);
             if (c->mean <= 0) fprintf(fp, "<div>-</div>");
-            else fprintf(fp, "<div%s>%.2f</div><div class=\"gbs\">%.1f GB/s</div>", c->mean == best ? " class=\"best\"" : "", c->mean, c->gbs);
+            else fprintf(fp, "<div%s>%.4f</div><div class=\"gbs\">%.1f GB/s<br>%s</div>", c->mean == best ? " class=\"best\"" : "", c->mean, c->gbs, c->kernel);
             fprintf(fp, "</td>");
         }
         fprintf(fp, "</tr>\n");

@@ -16,6 +16,15 @@ Files written:
   fuzz_vectors.json     seeded random cases over sigma/n/m incl. m>32, m>64, periodic texts
   deviations.json       documented reference deviations (EPSM tail miss, SO/BNDM straddle)
   english_vectors.json  counts on english_excerpt.txt (first 256 KiB of englishTexts/bible.txt)
+  config5_vectors.json  BASELINE config 5's alphabets (sigma 2, 32, 256) x every length of src/sets.h:25
+                        (2 .. 4096) on 2 MiB counter-based texts
+  english_bible_world192.txt.xz + english_corpus_vectors.json
+                        BASELINE config 4's unit: data/englishTexts as getText loads it through index.txt
+                        (smart.c:95-138: bible.txt then world192.txt, 6,520,792 bytes), xz-compressed DATA,
+                        and the reference's counts on it for every length of sets.h:25
+
+    python tests/golden/gen_golden.py                 # everything
+    python tests/golden/gen_golden.py config5 english_corpus   # only these
 """
 import json
 import os
@@ -211,10 +220,92 @@ def english_vectors():
                                   "rows": rows})
 
 
+SETS_H_25 = (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096)  # src/sets.h:25
+MIN_M = {"raita": 2, "hash3": 3, "hash5": 5, "hash8": 8, "sbndm": 2}  # below: the reference returns -1 (raita.c:37, hash3.c:31, ...)
+
+
+def agreed(c, m):
+    """The one count all applicable reference algorithms returned (-1 exactly where the algorithm does not apply)."""
+    vals = set()
+    for a, v in c.items():
+        if m < MIN_M.get(a, 1):
+            assert v == -1, (a, m, v)
+        elif v is not None:
+            vals.add(v)
+    assert len(vals) == 1, (m, c)
+    return vals.pop()
+
+
+
+def config5_vectors():
+    """sigma in {2, 32, 256}, every length of sets.h:25, patterns cut at three offsets of a 2 MiB text
+    (the last one ends 1 byte before the text does, as setOfRandomPatterns draws k < n-m, smart.c:153)."""
+    n = (2 << 20) + 12345
+    rows = []
+    for sigma in (2, 32, 256):
+        seed = 0xC0F5 + sigma
+        T = po.gen_text(seed, sigma, 0, n)
+        for m in SETS_H_25:
+            for k in (4321, n // 2 + 7, n - m - 1):
+                P = T[k:k + m].copy()
+                rows.append({"sigma": sigma, "seed": seed, "n": n, "m": m, "k": k, "count": agreed(ref_counts(P, T), m)})
+    dump("config5_vectors.json", {"text": "oracle_gen_text(seed, sigma, 0, n)", "pattern": "T[k:k+m]", "rows": rows})
+
+
+def get_text(path, tsize):
+    """getText of src/smart.c:95-138: the files named between '#' marks in <path>/index.txt, in order,
+    concatenated and cut at tsize bytes."""
+    out = bytearray()
+    with open(os.path.join(path, "index.txt"), "rb") as f:
+        idx = f.read()
+    i = 0
+    while i < len(idx) and len(out) < tsize:
+        if idx[i:i + 1] == b"#":
+            j = idx.index(b"#", i + 1)
+            with open(os.path.join(path, idx[i + 1:j].decode()), "rb") as g:
+                out += g.read(tsize - len(out))
+            i = j + 1
+        else:
+            i += 1
+    return bytes(out)
+
+
+def english_corpus():
+    import hashlib
+    import lzma
+    data = get_text("/root/reference/data/englishTexts", 1 << 30)
+    assert len(data) == 6520792 and hashlib.md5(data[:4047392]).hexdigest() == "93fb92788b569c0387a50f4c99720ee7" \
+        and hashlib.md5(data[4047392:]).hexdigest() == "30500a27cb7a15e6f2fa0032b06e06c3"  # SURVEY.md §8c
+    with open(os.path.join(OUT, "english_bible_world192.txt.xz"), "wb") as f:
+        f.write(lzma.compress(data, preset=9 | lzma.PRESET_EXTREME))
+    T = np.frombuffer(data, dtype=np.uint8)
+    n = len(T)
+    rows = []
+    for m in SETS_H_25:
+        for k in (0, 12345, 524288, 4047392 - m // 2, n - m - 1):  # the fourth straddles the two files
+            P = T[k:k + m].copy()
+            rows.append({"m": m, "k": k, "count": agreed(ref_counts(P, T), m)})
+    # SURVEY.md §8c starter table, english rows: the first 1,048,576 bytes (default -tsize, smart.c:416)
+    n1 = 1048576
+    want = {(2, 0): 52, (2, 12345): 6035, (2, 524288): 33904, (2, n1 - 3): 6248, (4, 0): 39, (4, 12345): 3952,
+            (4, 524288): 1097, (4, n1 - 5): 1731, (8, 0): 1, (8, 12345): 125, (8, 524288): 18, (8, n1 - 9): 4,
+            (32, 0): 1, (32, 12345): 3, (32, 524288): 1, (32, n1 - 33): 1, (256, 0): 1, (256, 12345): 1}
+    prefix_rows = []
+    for (m, k), cnt in sorted(want.items()):
+        got = agreed(ref_counts(T[k:k + m].copy(), T[:n1]), m)
+        assert got == cnt, (m, k, got, cnt)
+        prefix_rows.append({"m": m, "k": k, "n": n1, "count": got})
+    dump("english_corpus_vectors.json", {
+        "text": "english_bible_world192.txt.xz = data/englishTexts/bible.txt + world192.txt (getText order), 6520792 bytes",
+        "md5": hashlib.md5(data).hexdigest(), "n": n, "rows": rows,
+        "survey_rows": prefix_rows, "survey_rows_text": "the first 1,048,576 bytes of the same text (SURVEY.md §8c table)"})
+
+
 if __name__ == "__main__":
     po.build(ref=True)
-    survey_vectors()
-    testc_cases()
-    fuzz_vectors()
-    deviations()
-    english_vectors()
+    todo = sys.argv[1:] or ["survey", "testc", "fuzz", "deviations", "english", "config5", "english_corpus"]
+    for name, fn in (("survey", survey_vectors), ("testc", testc_cases), ("fuzz", fuzz_vectors),
+                     ("deviations", deviations), ("english", english_vectors), ("config5", config5_vectors),
+                     ("english_corpus", english_corpus)):
+        if name in todo:
+            fn()

@@ -50,8 +50,47 @@ def test_latest_bench_line_agrees_with_its_rocprof_summary():
     assert abs(avg_ms - d["roofline"]["kernel_ms"]) / d["roofline"]["kernel_ms"] < 0.08, (avg_ms, d["roofline"]["kernel_ms"])
 
 
-def test_splitmix_and_traffic_table():
+def test_splitmix_and_traffic_table(tmp_path):
+    """roofline.traffic is bound to the kernel source it was profiled on: the table records the sha256 of
+    kernels.hip, and bench.py reports null (and why) for any other source."""
     assert bench.splitmix64(0) == 0xE220A8397B1DCDAF  # the published first output of SplitMix64
-    t = bench.load_traffic("hor_scan", "hor_m32_sigma128_gib1")
-    assert t is not None and 1.0 <= t / 2**30 < 1.05
-    assert bench.load_traffic("hor_scan", "no_such_workload") is None
+    table = {"_source": {"kernels_hip_sha256": bench.kernels_sha256(), "commit": "abc1234", "summary": "profiles/rXX/x.csv"},
+             "hor_scan": {"hor_m32_sigma128_gib1": 1082204320}}
+    f = tmp_path / "pmc_traffic.json"
+    f.write_text(json.dumps(table))
+    t, src = bench.load_traffic("hor_scan", "hor_m32_sigma128_gib1", path=str(f))
+    assert t == 1082204320 and "abc1234" in src and "profiles/rXX/x.csv" in src
+    t, why = bench.load_traffic("hor_scan", "no_such_workload", path=str(f))
+    assert t is None and "no PMC pass" in why
+    table["_source"]["kernels_hip_sha256"] = "0" * 64  # profiled on another kernel source
+    f.write_text(json.dumps(table))
+    t, why = bench.load_traffic("hor_scan", "hor_m32_sigma128_gib1", path=str(f))
+    assert t is None and "not measured for this kernel source" in why
+    # the committed table: either it matches the committed kernels.hip, or bench.py says null
+    t, src = bench.load_traffic("hor_scan", "hor_m32_sigma128_gib1")
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    if committed.get("_source", {}).get("kernels_hip_sha256") == bench.kernels_sha256():
+        assert t is not None and 1.0 <= t / 2**30 < 1.05
+    else:
+        assert t is None and src
+
+
+def test_plain_multi_gpu_invocation_launches_its_ranks():
+    """`python bench.py --gpus 2` without torchrun: the process starts the two ranks itself (before it
+    touches a GPU) through torch.distributed.run on 127.0.0.1; --check-launch makes the ranks only
+    rendezvous (gloo), all-reduce their rank ids and report — no GPU needed."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d == {"check_launch": True, "n_gpus": 2, "rank_id_sum": 3, "launched_by": "torch.distributed.run",
+                 "master_addr": "127.0.0.1"}
+    # a rank count that does not match the launcher's world size is refused
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
+                         env=env2, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stderr + bad.stdout)
