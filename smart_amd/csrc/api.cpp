@@ -806,6 +806,7 @@ bool batch_reserve(DeviceCtx* d, size_t blob_bytes, size_t k)
 }
 
 struct BatchPlan { uint32_t halo, prefer_packed, sparse, so_off; size_t off; };
+constexpr uint64_t kOneGridMaxText = 32ull << 20;  // pattern sets over texts up to this size run as ONE grid per kernel
 
 // Build the K blobs on the host and place them in the device's arena; pre_ms[k] = host table construction of
 // pattern k + its share of the upload.  plans[k].off = offset of blob k in the arena.
@@ -824,7 +825,7 @@ int batch_upload(DeviceCtx* d, int algo, const uint8_t* const* P, uint32_t m, ui
         plans[k].off = total;
         total += blobs[k].size();  // multiples of 256
     }
-    if (!batch_reserve(d, total, K)) return SMARTGPU_ERR_NOMEM;
+    if (!batch_reserve(d, total + 256 + K * sizeof(sg::ScanArgs), K)) return SMARTGPU_ERR_NOMEM;
     const double t_up = now_ms();
     // pinned staging -> arena, as many blobs per copy as the staging buffer holds
     for (uint32_t k = 0; k < K;) {
@@ -867,6 +868,64 @@ sg::ScanArgs batch_args(const BatchPlan& bp, const DeviceCtx* d, uint32_t m, con
     return a;
 }
 
+
+// Enqueue the searches of a pattern set on the device's stream; counts go to d->batch_counts[0..K).
+// Small texts (SMART's stock 1 MiB: a search is 64 workgroups and 3 us, less than its launch costs the host):
+// the set runs as ONE grid per kernel, gridDim.y = patterns (sg::launch_scan_set) — the per-pattern arguments
+// go up as one array behind the tables; patterns are grouped by the kernel and grid their plans choose.
+// Larger texts: K launches back to back (each fills the chip on its own), with one HIP event per pattern
+// if per-pattern device times are wanted.  run_ms (or NULL): device time per pattern; in the one-grid form
+// a group's time divided by its patterns.
+int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, uint32_t m, const smartgpu_text* text,
+                  uint64_t off, uint64_t n, uint32_t K, bool timed, std::vector<std::pair<uint32_t, uint32_t>>* groups_out)
+{
+    HIP_TRY(hipMemsetAsync(d->batch_counts, 0, static_cast<size_t>(K) * 8, d->stream), return SMARTGPU_ERR_HIP);
+    if (timed)
+        while (d->batch_events.size() < static_cast<size_t>(K) + 1) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e), return SMARTGPU_ERR_HIP);
+            d->batch_events.push_back(e);
+        }
+    if (groups_out) groups_out->clear();
+    if (n > kOneGridMaxText || K == 1) {
+        if (timed) HIP_TRY(hipEventRecord(d->batch_events[0], d->stream), return SMARTGPU_ERR_HIP);
+        for (uint32_t k = 0; k < K; ++k) {
+            const sg::ScanArgs a = batch_args(plans[k], d, m, text, off, n, d->batch_counts + k);
+            HIP_TRY(sg::launch_scan(algo, a, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
+            if (timed) HIP_TRY(hipEventRecord(d->batch_events[k + 1], d->stream), return SMARTGPU_ERR_HIP);
+            if (groups_out) groups_out->push_back({k, 1u});
+        }
+        return SMARTGPU_OK;
+    }
+    // one grid per group of patterns whose plans lead to the same kernel and grid
+    auto key = [&](uint32_t k) { return (plans[k].prefer_packed ? 4u : 0u) | (plans[k].so_off ? 2u : 0u) | (plans[k].sparse ? 1u : 0u); };
+    std::vector<uint32_t> order(K);
+    for (uint32_t k = 0; k < K; ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
+    sg::ScanArgs* host_items = reinterpret_cast<sg::ScanArgs*>(d->pinned);
+    for (uint32_t i = 0; i < K; ++i)
+        host_items[i] = sg::prepare_scan_args(algo, batch_args(plans[order[i]], d, m, text, off, n, d->batch_counts + order[i]));
+    sg::ScanArgs* dev_items = reinterpret_cast<sg::ScanArgs*>(d->arena + d->arena_bytes - ((static_cast<size_t>(K) * sizeof(sg::ScanArgs) + 255) & ~size_t(255)));
+    HIP_TRY(hipMemcpyAsync(dev_items, host_items, static_cast<size_t>(K) * sizeof(sg::ScanArgs), hipMemcpyHostToDevice, d->stream),
+            return SMARTGPU_ERR_HIP);
+    uint32_t ev = 0;
+    if (timed) HIP_TRY(hipEventRecord(d->batch_events[ev++], d->stream), return SMARTGPU_ERR_HIP);
+    for (uint32_t i = 0; i < K;) {
+        uint32_t j = i;
+        while (j < K && key(order[j]) == key(order[i])) ++j;
+        HIP_TRY(sg::launch_scan_set(algo, host_items[i], dev_items + i, j - i, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
+        if (timed) HIP_TRY(hipEventRecord(d->batch_events[ev++], d->stream), return SMARTGPU_ERR_HIP);
+        if (groups_out) groups_out->push_back({i, j - i});
+        i = j;
+    }
+    // groups_out indexes the sorted order; remember it for the caller through the pinned array's tail
+    if (groups_out) {
+        uint32_t* ord = reinterpret_cast<uint32_t*>(d->pinned + d->pinned_bytes - static_cast<size_t>(K) * 4);
+        for (uint32_t i = 0; i < K; ++i) ord[i] = order[i];
+    }
+    return SMARTGPU_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -883,32 +942,26 @@ int smartgpu_search_batch64(int algo, const uint8_t* const* P, uint32_t m, uint3
     const int up = batch_upload(d, algo, P, m, K, plans, pre_ms);  // preprocessing phase
     if (up != SMARTGPU_OK) return up;
     const bool timed = run_ms != nullptr;
-    if (timed)
-        while (d->batch_events.size() < static_cast<size_t>(K) + 1) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreate(&e), return SMARTGPU_ERR_HIP);
-            d->batch_events.push_back(e);
-        }
-    // searching phase: K launches back to back, one read-back
+    // searching phase: the set's launches, one read-back
+    std::vector<std::pair<uint32_t, uint32_t>> groups;
     const double t0 = now_ms();
-    HIP_TRY(hipMemsetAsync(d->batch_counts, 0, static_cast<size_t>(K) * 8, d->stream), return SMARTGPU_ERR_HIP);
-    if (timed) HIP_TRY(hipEventRecord(d->batch_events[0], d->stream), return SMARTGPU_ERR_HIP);
-    for (uint32_t k = 0; k < K; ++k) {
-        const sg::ScanArgs a = batch_args(plans[k], d, m, text, off, n, d->batch_counts + k);
-        HIP_TRY(sg::launch_scan(algo, a, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
-        if (timed) HIP_TRY(hipEventRecord(d->batch_events[k + 1], d->stream), return SMARTGPU_ERR_HIP);
-    }
+    const int eq = batch_enqueue(d, algo, plans, m, text, off, n, K, timed, &groups);
+    if (eq != SMARTGPU_OK) return eq;
     HIP_TRY(hipMemcpyAsync(d->pinned_counts, d->batch_counts, static_cast<size_t>(K) * 8, hipMemcpyDeviceToHost, d->stream),
             return SMARTGPU_ERR_HIP);
     HIP_TRY(hipStreamSynchronize(d->stream), return SMARTGPU_ERR_HIP);
     const double wall = now_ms() - t0;
     for (uint32_t k = 0; k < K; ++k) counts[k] = d->pinned_counts[k];
-    if (timed)
-        for (uint32_t k = 0; k < K; ++k) {
+    if (timed) {
+        const bool one_grid = !(n > kOneGridMaxText || K == 1);
+        const uint32_t* ord = reinterpret_cast<const uint32_t*>(d->pinned + d->pinned_bytes - static_cast<size_t>(K) * 4);
+        for (size_t g = 0; g < groups.size(); ++g) {
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, d->batch_events[k], d->batch_events[k + 1]), return SMARTGPU_ERR_HIP);
-            run_ms[k] = ms;
+            HIP_TRY(hipEventElapsedTime(&ms, d->batch_events[g], d->batch_events[g + 1]), return SMARTGPU_ERR_HIP);
+            for (uint32_t i = groups[g].first; i < groups[g].first + groups[g].second; ++i)
+                run_ms[one_grid ? ord[i] : i] = ms / groups[g].second;
         }
+    }
     if (batch_ms) *batch_ms = wall;
     g_last_pre_ms = pre_ms ? pre_ms[K - 1] : 0.0;
     g_last_run_ms = wall / K;
@@ -1140,16 +1193,11 @@ int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint
     auto launch_shard = [&](int g) -> int {
         DeviceCtx* d = ctx[g];
         HIP_TRY(hipSetDevice(text->devices[g]), return SMARTGPU_ERR_HIP);
-        HIP_TRY(hipMemsetAsync(d->batch_counts, 0, static_cast<size_t>(K) * 8, d->stream), return SMARTGPU_ERR_HIP);
         // shard g counts the starts it owns: its first (begin[g+1]-begin[g]) positions
         const uint64_t own = text->begin[g + 1] - text->begin[g];
         const uint64_t have = smartgpu_text_length(text->shards[g]);
         const uint64_t span = std::min<uint64_t>(have, own + m - 1);
-        for (uint32_t j = 0; j < K; ++j) {
-            const sg::ScanArgs a = batch_args(plans[g][j], d, m, text->shards[g], 0, span, d->batch_counts + j);
-            HIP_TRY(sg::launch_scan(algo, a, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
-        }
-        return SMARTGPU_OK;
+        return batch_enqueue(d, algo, plans[g], m, text->shards[g], 0, span, K, false, nullptr);
     };
     int rc = SMARTGPU_OK;
     if (distinct) {

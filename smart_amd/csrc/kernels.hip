@@ -198,9 +198,10 @@ static __device__ __forceinline__ void tile_park(uint8_t* txt, uint32_t i0, cons
 //      of the window's last q = VAR bytes, h = sum T[e-k] * 2^k mod 256; its zero entry (the hash
 //      of the pattern's last q-gram) is the flag, stored with the shift applied after a candidate
 template <int THREADS, int L, bool LONG, int VAR>  // LONG: m-1 > back halo, windows are completed in HBM
-__global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a, uint64_t tile_first,
-                                                    uint32_t ntiles)
+__global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a1, uint64_t tile_first,
+                                                    uint32_t ntiles, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, H = a.halo, H16 = round16(H);
@@ -337,9 +338,10 @@ __device__ __forceinline__ uint32_t bp_addr(uint32_t P)
 // 2^(m-1-i), so of a window longer than 32 bytes only the last 32 still count and nothing has to
 // be subtracted; an equal hash is confirmed byte by byte (LDS through the halo, then memory).
 template <bool KR>
-__global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t tile_first,
-                                                          uint32_t ntiles)
+__global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a1, uint64_t tile_first,
+                                                          uint32_t ntiles, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = kBpThreads * kBpL;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, H = a.halo, H16 = round16(H);
@@ -518,9 +520,10 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a, uint64_t t
 // LDS: u16 bc[256] | u16 gs[m] | pattern tail | text [tile0-H16, tile0+TB)
 // ---------------------------------------------------------------------------
 template <int THREADS, int L, bool LONG>  // LONG: m-1 > back halo
-__global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_first,
-                                                   uint32_t ntiles)
+__global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_first,
+                                                   uint32_t ntiles, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, H = a.halo, H16 = round16(H);
@@ -647,9 +650,10 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a, uint64_t tile_fir
 // w-k), an occurrence moves by the period of the (prefix of the) pattern, which the host stores
 // after the fingerprint.
 template <int THREADS, int L, bool LONG, bool SIMPLE>  // LONG: m > 32, prefix hits are verified
-__global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_first,
-                                                     uint32_t ntiles)
+__global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_first,
+                                                     uint32_t ntiles, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32, H16 = 32;
@@ -783,8 +787,9 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a, uint64_t tile_f
 // LDS: u32 B[256][W] | P[0..w) | text [tile0-256, tile0+TB)
 // ---------------------------------------------------------------------------
 template <int THREADS, int L, int W, bool LONG>  // LONG: m > kBndmlWindow
-__global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a, uint64_t tile_first, uint32_t ntiles)
+__global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a1, uint64_t tile_first, uint32_t ntiles, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     constexpr uint32_t H16 = 256;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -934,9 +939,10 @@ __global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a, uint64_t tile_
 // depend on the state), then the recurrence runs on registers.
 // ---------------------------------------------------------------------------
 template <int THREADS, int L, bool LONG>  // LONG: m > 32, prefix hits are verified
-__global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a, uint64_t tile_first,
-                                                   uint32_t ntiles)
+__global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a1, uint64_t tile_first,
+                                                   uint32_t ntiles, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     static_assert((L / 16) % 2 == 1, "L/16 must be odd (LDS bank spread)");
     static_assert(L % 16 == 0 && TB % (THREADS * 16) == 0, "whole 16-byte rows");
@@ -1097,9 +1103,10 @@ __device__ __forceinline__ void kmp_chunk(const uint4& v, uint32_t j_base, uint3
 }
 
 template <int THREADS, int L>
-__global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a, uint64_t tile_first,
-                                                    uint32_t ntiles)
+__global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a1, uint64_t tile_first,
+                                                    uint32_t ntiles, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     static_assert((L / 16) % 2 == 1, "L/16 must be odd (LDS bank spread)");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1393,9 +1400,10 @@ __device__ __forceinline__ uint4 run_piece(const LineIo& io, int c)
     } while (0)
 
 template <bool PREFIX>  // PREFIX: m > 255 — the automaton of the 255-byte prefix; hits are verified
-__global__ __launch_bounds__(kRunWaves * 64) void kmp_runs1(ScanArgs a, uint32_t run_len, uint64_t nruns,
-                                                       uint32_t dfa_off)
+__global__ __launch_bounds__(kRunWaves * 64) void kmp_runs1(ScanArgs a1, uint32_t run_len, uint64_t nruns,
+                                                       uint32_t dfa_off, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1536,9 +1544,10 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs1(ScanArgs a, uint32_t
 }
 
 // The failure links followed per byte (the reference's loop, kmp.c:55-66), A/B only: smartgpu_tune(3,2).
-__global__ __launch_bounds__(256) void kmp_links_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
-                                                uint32_t)
+__global__ __launch_bounds__(256) void kmp_links_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
+                                                uint32_t, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1634,8 +1643,9 @@ __global__ __launch_bounds__(256) void kmp_links_runs(ScanArgs a, uint32_t run_l
 // aligned like SO: the 1 enters at bit 32-w, the hit is the sign bit, bytes outside a lane's
 // range map to the mask 0 (no prefix survives).
 template <bool LONG, bool AND>  // LONG: m > 32, hits of the 32-byte prefix are verified
-__global__ __launch_bounds__(kRunWaves * 64) void so_runs1(ScanArgs a, uint32_t run_len, uint64_t nruns)
+__global__ __launch_bounds__(kRunWaves * 64) void so_runs1(ScanArgs a1, uint32_t run_len, uint64_t nruns, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1848,8 +1858,9 @@ __device__ __forceinline__ uint32_t lshl_or_now(uint32_t a, uint32_t b)
 #define SG_ABLATE 0  // experiments only (wrong counts): 1 no gathers, 2 no recurrence, 4 no parking, 8 no fetch after line 0
 #endif
 template <bool LONG>  // LONG: m > 29, hits of the 29-byte prefix are verified
-__global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a, uint32_t run_len, uint64_t nruns)
+__global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < kSoWindow ? m : kSoWindow;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -2083,9 +2094,10 @@ __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base,
 // (profiles/r02, same box, 1 GiB rand128): tables below 64 KB 0.194-0.201 ms behind the swap loader against
 // 0.200-0.210; the full 64 KB table (63+ states) 0.220 against 0.210 — the launcher picks by table size.
 template <bool PREFIX, bool RUNIO>  // PREFIX: m > 254 — the automaton of the 254-byte prefix; hits are verified
-__global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t run_len, uint64_t nruns,
-                                                           uint32_t dfa_off)
+__global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
+                                                           uint32_t dfa_off, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -2235,8 +2247,9 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a, uint32_t 
 
 // The first runs kernel: shared 1 KB table, 64-byte steps, [run][80 B] slabs (A/B only).
 template <bool LONG>
-__global__ __launch_bounds__(256) void so_runs64(ScanArgs a, uint32_t run_len, uint64_t nruns)
+__global__ __launch_bounds__(256) void so_runs64(ScanArgs a1, uint32_t run_len, uint64_t nruns, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -2437,9 +2450,10 @@ static __device__ __attribute__((noinline)) uint32_t epsm_verify(const uint8_t* 
 // ALGO only tags the instantiation (rocprofv3 shows packed_scan<256, 4, 5, ..> for
 // EPSM and packed_scan<256, 4, 0, ..> for Horspool's short-pattern regime).
 template <int THREADS, int ROWS, int ALGO, int MODE, int POLICY>
-__global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a, uint64_t row_first,
-                                                       uint64_t nrows)
+__global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row_first,
+                                                       uint64_t nrows, const ScanArgs* __restrict__ batch)
 {
+    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     // POLICY 0: A non-temporal, B cached (default); 1: both cached; 3: one nt load + shuffle.
     // (Both loads nt measured 62-67 %: the second load must find the line still cached.  A
     // ballot/SGPR formulation of the first-dword test measured 59-73 %: scalar-unit bound.)
@@ -2674,6 +2688,10 @@ hipError_t launch_probe_read(const uint8_t* text, uint64_t n, unsigned long long
 namespace {
 
 struct TileRange { uint64_t first; uint32_t count; };
+// A pattern set in ONE grid: while set, every scan launch uses gridDim.y = count and hands the kernels the
+// device array of per-pattern arguments (they take argument set blockIdx.y instead of the by-value one).
+struct BatchCtx { const ScanArgs* items; uint32_t count; };
+thread_local BatchCtx g_batch = {nullptr, 1};
 
 // tiles of `tb` absolute offsets intersecting [lo, hi)
 TileRange tiles_for(uint64_t lo, uint64_t hi, uint64_t tb)
@@ -2708,13 +2726,14 @@ hipError_t launch_tiled(K kernel, const ScanArgs& a, TileRange tr, int threads, 
     if (g_tune[4]) wgs_per_cu = g_tune[4];  // A/B: workgroups per CU of the tile kernels
     uint32_t grid = (uint32_t)num_cus * (uint32_t)wgs_per_cu;
     if (grid > tr.count) grid = tr.count;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, stream, a, tr.first, tr.count);
+    hipLaunchKernelGGL(kernel, dim3(grid, g_batch.count), dim3(threads), lds, stream, a, tr.first, tr.count, g_batch.items);
     return hipGetLastError();
 }
 
 }  // namespace
 
 int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 // skip algorithms use the packed matcher up to this m (crossovers measured on 1 GiB rand128
 // with non-temporal tile loads, profiles/r01): HOR/TUNEDBM/RAITA 7, BM 8, BNDM 11, QS 14, HASH3/5/8 32/64/28
 static constexpr uint32_t packed_max_m(int algo)
@@ -2817,14 +2836,14 @@ static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus,
 #define SG_SO_RUNS1(L_, A_)                                                                               \
     do {                                                                                                 \
         allow_lds(reinterpret_cast<const void*>(so_runs1<L_, A_>), lds);                                  \
-        hipLaunchKernelGGL((so_runs1<L_, A_>), dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, \
-                           (uint32_t)L, (uint64_t)tr.count);                                             \
+        hipLaunchKernelGGL((so_runs1<L_, A_>), dim3((uint32_t)grid, g_batch.count), dim3(64 * kRunWaves), lds, stream, a, \
+                           (uint32_t)L, (uint64_t)tr.count, g_batch.items);                              \
     } while (0)
 #define SG_SO_RUNS(L_)                                                                                   \
     do {                                                                                                 \
         allow_lds(reinterpret_cast<const void*>(so_runs<L_>), lds);                                      \
-        hipLaunchKernelGGL((so_runs<L_>), dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a,    \
-                           (uint32_t)L, (uint64_t)tr.count);                                             \
+        hipLaunchKernelGGL((so_runs<L_>), dim3((uint32_t)grid, g_batch.count), dim3(64 * kRunWaves), lds, stream, a, \
+                           (uint32_t)L, (uint64_t)tr.count, g_batch.items);                              \
     } while (0)
     if (shift_and) { if (m > 32) SG_SO_RUNS1(true, true); else SG_SO_RUNS1(false, true); }
     else if (g_tune[6] == 4) { if (m > 32) SG_SO_RUNS1(true, false); else SG_SO_RUNS1(false, false); }
@@ -2854,8 +2873,8 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
         uint64_t grid = ((uint64_t)tr.count + 255) / 256;
         const uint64_t cap = (uint64_t)num_cus * 4;
         if (grid > cap) grid = cap;
-        hipLaunchKernelGGL(kmp_links_runs, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L,
-                           (uint64_t)tr.count, dfa_off);
+        hipLaunchKernelGGL(kmp_links_runs, dim3((uint32_t)grid, g_batch.count), dim3(256), lds, stream, a, (uint32_t)L,
+                           (uint64_t)tr.count, dfa_off, g_batch.items);
         return hipGetLastError();
     }
     // one 1024-thread workgroup per CU shares the table (<= 64 KB) next to 16 x 4 KB of slabs
@@ -2877,8 +2896,8 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
 #define SG_KMP_RUNS(K_, OFF_)                                                                            \
     do {                                                                                                 \
         if (lds > 64 * 1024) allow_lds(reinterpret_cast<const void*>(K_), lds);                          \
-        hipLaunchKernelGGL(K_, dim3((uint32_t)grid), dim3(64 * kRunWaves), lds, stream, a, (uint32_t)L,  \
-                           (uint64_t)tr.count, (uint32_t)(OFF_));                                        \
+        hipLaunchKernelGGL(K_, dim3((uint32_t)grid, g_batch.count), dim3(64 * kRunWaves), lds, stream, a, (uint32_t)L, \
+                           (uint64_t)tr.count, (uint32_t)(OFF_), g_batch.items);                         \
     } while (0)
     if (v1) {
         if (m > kKmpDfaMaxM) SG_KMP_RUNS(kmp_runs1<true>, dfa_off); else SG_KMP_RUNS(kmp_runs1<false>, dfa_off);
@@ -2908,8 +2927,8 @@ static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stre
     const uint64_t cap = (uint64_t)num_cus * (g_tune[4] ? g_tune[4] : 16);
     if (grid > cap) grid = cap;
 #define SG_PACKED(M_, P_)                                                                           \
-    hipLaunchKernelGGL((packed_scan<kEpsmT, 4, ALGO, M_, P_>), dim3((uint32_t)grid), dim3(kEpsmT), 128, \
-                       stream, a, tr.first, (uint64_t)tr.count)
+    hipLaunchKernelGGL((packed_scan<kEpsmT, 4, ALGO, M_, P_>), dim3((uint32_t)grid, g_batch.count), dim3(kEpsmT), 128, \
+                       stream, a, tr.first, (uint64_t)tr.count, g_batch.items)
 #define SG_PACKED_POLICY(M_)                                                 \
     do {                                                                     \
         if (g_tune[7] == 1) SG_PACKED(M_, 1);                                \
@@ -2963,25 +2982,46 @@ hipError_t launch_find(const ScanArgs& a, unsigned long long* out, unsigned long
     return hipGetLastError();
 }
 
-hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream)
+// What launch_scan fills in for the kernels before they run: where the packed matcher finds the fingerprint
+// in this algorithm's blob, and the Shift-Or masks of SO / SA.  Applied to the by-value arguments of a single
+// launch and, by the caller, to every element of a pattern set's argument array (launch_scan_set).
+ScanArgs prepare_scan_args(int algo, ScanArgs a)
 {
-    if (a.s_end <= a.s_begin) return hipSuccess;
+    const uint32_t m = a.m;
+    switch (algo) {
+        case SMARTGPU_KR: a.fp_off = kTableOff + 4; break;  // after the pattern's hash
+        case SMARTGPU_BM: a.fp_off = kTableOff + ((1536 + 2 * (m + 1) + 3) & ~3u); break;  // after first, second, bc, gs, safe shift
+        case SMARTGPU_BNDML: a.fp_off = m > 32 ? kTableOff + 1024 * 2 + 4 : kTableOff + 1024; break;  // after the masks (W = 2) and the period / after B[256]
+        case SMARTGPU_SBNDM:
+        case SMARTGPU_BNDM: a.fp_off = kTableOff + 1024; break;  // after B[256]
+        case SMARTGPU_EPSM: a.fp_off = kTableOff; break;
+        case SMARTGPU_SO: a.so_off = kTableOff; break;
+        case SMARTGPU_SA: a.so_off = g_tune[6] == 3 ? kTableOff + 1024 : kTableOff; break;
+        case SMARTGPU_KMP: break;
+        default: a.fp_off = kTableOff + 768; break;  // the Horspool family: after the u16 and u8 tables
+    }
+    return a;
+}
+
+hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t stream)
+{
+    if (a_in.s_end <= a_in.s_begin) return hipSuccess;
+    const bool rerouted = a_in.so_off != 0 && algo != SMARTGPU_SO && algo != SMARTGPU_SA;  // plans of 2-3-symbol patterns (api.cpp)
+    const ScanArgs a = prepare_scan_args(algo, a_in);
     const uint32_t m = a.m;
     // A pattern over two or three symbols, 16 bytes or longer: no byte, pair or dword of it tells a
     // window from its neighbours, so the skip kernels move one or two bytes at a time and the packed
     // matcher tests all four fingerprint dwords at every alignment (33-45 % on rand2, all of them).
     // The branch-free bit-parallel runs kernel does not care what the bytes are (66-70 %): plans of
     // such patterns carry Shift-Or masks as well (api.cpp build_blob) and count with it.
-    if (a.so_off != 0 && g_tune[0] == 0) return launch_so_runs(a, false, num_cus, stream);
+    if (rerouted && g_tune[0] == 0) return launch_so_runs(a, false, num_cus, stream);
     switch (algo) {
         case SMARTGPU_TUNEDBM:  // hor_scan<.., 0> is Tuned BM's loop (see the kernel's comment)
         case SMARTGPU_HOR: {
             const uint32_t H = a.halo;
             const int regime = (a.prefer_packed && g_tune[0] == 0) ? 3 : hor_regime(m);
             if (regime == 3) {
-                ScanArgs b = a;
-                b.fp_off = kTableOff + 768;  // fingerprint sits after the u16 and u8 tables
-                return launch_packed<SMARTGPU_HOR>(b, num_cus, stream);
+                return launch_packed<SMARTGPU_HOR>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
             }
             if (regime == 2) {
                 const size_t lds = kBpTabBytes + r16(H + 1) + kBpTextBytes;
@@ -2998,9 +3038,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 // Short patterns, like the skip algorithms': the packed matcher (72-77 %).  Only the low m bits
                 // of the rolled hash can be compared, so one window end in 2^m is confirmed (m = 8: 32 %,
                 // m = 12: 50 % of 8 TB/s), and below 8 the rolling form needs the outgoing byte (15 %).
-                ScanArgs b = a;
-                b.fp_off = kTableOff + 4;  // after the pattern's hash
-                return launch_packed<SMARTGPU_HOR>(b, num_cus, stream);
+                return launch_packed<SMARTGPU_HOR>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
             }
             const uint32_t H = a.halo;
             const size_t lds = kBpTabBytes + r16(H + 1) + kBpTextBytes;
@@ -3014,9 +3052,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
         case SMARTGPU_QS: {  // the Horspool family on hor_scan's tiles; short patterns: packed regime as HOR
             const uint32_t H = a.halo;
             if ((a.prefer_packed && g_tune[0] == 0) || hor_regime(m, algo) == 3) {
-                ScanArgs b = a;
-                b.fp_off = kTableOff + 768;
-                return launch_packed<SMARTGPU_HOR>(b, num_cus, stream);
+                return launch_packed<SMARTGPU_HOR>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
             }
             const size_t lds = 512 + r16(H + 1) + ((r16(H) + (size_t)kHorT * kHorL + 16 + 63) & ~(size_t)63);  // whole 64-byte blocks: tile_at() permutes inside them
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
@@ -3035,9 +3071,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
         }
         case SMARTGPU_BM: {
             if ((m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
-                ScanArgs b = a;
-                b.fp_off = kTableOff + ((1536 + 2 * (m + 1) + 3) & ~3u);  // after first, second, bc, gs, safe shift
-                return launch_packed<SMARTGPU_BM>(b, num_cus, stream);
+                return launch_packed<SMARTGPU_BM>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
             }
             const uint32_t H = a.halo;
             const size_t lds = 1536 + r16(2 * (m + 1)) + r16(H + 1) + ((r16(H) + (size_t)kBmT * kBmL + 63) & ~(size_t)63);  // whole 64-byte blocks (tile_at)
@@ -3050,9 +3084,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             if (m > 32) {  // multi-word vectors; m <= 32 is plain BNDM (bndml.c:44-75): falls through
                 const uint32_t w = m < kBndmlWindow ? m : kBndmlWindow;
                 if (a.prefer_packed && g_tune[0] == 0) {
-                    ScanArgs b = a;
-                    b.fp_off = kTableOff + 1024 * 2 + 4;  // after the masks (W = 2) and the period
-                    return launch_packed<SMARTGPU_BNDM>(b, num_cus, stream);
+                    return launch_packed<SMARTGPU_BNDM>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
                 }
                 const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
 #define SG_BNDML(W_)                                                                                      \
@@ -3069,9 +3101,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
         case SMARTGPU_SBNDM:
         case SMARTGPU_BNDM: {
             if ((m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
-                ScanArgs b = a;
-                b.fp_off = kTableOff + 1024;  // after B[256]
-                return launch_packed<SMARTGPU_BNDM>(b, num_cus, stream);
+                return launch_packed<SMARTGPU_BNDM>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
             }
             const uint32_t w = m < 32 ? m : 32;
             const size_t lds = 1024 + ((32 + (size_t)kBndmT * kBndmL + 63) & ~(size_t)63);  // whole 64-byte blocks (tile_at)
@@ -3098,18 +3128,16 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
                 if (grid > cap) grid = cap;
                 const size_t lds = 1040 + 4 * (size_t)kRunSlab;
                 if (m > 32)
-                    hipLaunchKernelGGL(so_runs64<true>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                    hipLaunchKernelGGL(so_runs64<true>, dim3((uint32_t)grid, g_batch.count), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count, g_batch.items);
                 else
-                    hipLaunchKernelGGL(so_runs64<false>, dim3((uint32_t)grid), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count);
+                    hipLaunchKernelGGL(so_runs64<false>, dim3((uint32_t)grid, g_batch.count), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count, g_batch.items);
                 return hipGetLastError();
             }
             if (g_tune[6] != 1 || algo == SMARTGPU_SA) {  // per-lane runs through LDS line slabs (tune[6]=1: LDS tiles, for A/B)
-                ScanArgs b = a;
-                // Shift-And counts in the complemented (Shift-Or) form by default: api.cpp build_blob; its own
-                // AND form (so_runs1<.., AND = true>, masks after the Shift-Or ones) with tune(6,3)
+                // a.so_off: prepare_scan_args (Shift-And counts in the complemented, Shift-Or form by default:
+                // api.cpp build_blob; its own AND form — so_runs1<.., AND = true>, masks after the Shift-Or ones — with tune(6,3))
                 const bool and_form = algo == SMARTGPU_SA && g_tune[6] == 3;
-                b.so_off = and_form ? kTableOff + 1024 : kTableOff;
-                return launch_so_runs(b, and_form, num_cus, stream);
+                return launch_so_runs(a, and_form, num_cus, stream);
             }
             const size_t lds = 1040 + (size_t)kSoT * kSoL + 32;
             const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kSoT * kSoL);
@@ -3137,12 +3165,20 @@ hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t str
             return launch_kmp_runs(a, num_cus, stream);
         }
         case SMARTGPU_EPSM: {
-            ScanArgs b = a;
-            b.fp_off = kTableOff;
-            return launch_packed<SMARTGPU_EPSM>(b, num_cus, stream);
+            return launch_packed<SMARTGPU_EPSM>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
         }
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_scan_set(int algo, const ScanArgs& first, const ScanArgs* device_items, uint32_t count, int num_cus,
+                           hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    g_batch = {device_items, count};
+    const hipError_t e = launch_scan(algo, first, num_cus, stream);
+    g_batch = {nullptr, 1};
+    return e;
 }
 
 hipError_t launch_generate(uint8_t* dst, uint64_t seed, int sigma, uint64_t off, uint64_t n,

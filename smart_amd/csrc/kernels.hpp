@@ -58,6 +58,12 @@ struct LaunchInfo {
 
 // Enqueue the scan for `algo` on `stream`; returns hipSuccess or the launch error.
 hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream);
+ScanArgs prepare_scan_args(int algo, ScanArgs a);  // what launch_scan fills in (fp_off, so_off of SO/SA)
+// The same for a pattern set in ONE grid (gridDim.y = count): `device_items` holds the per-pattern arguments
+// in device memory; all of them must lead launch_scan to the same kernel and grid as `first` does (same
+// algorithm, m, range, prefer_packed, sparse, so_off != 0) — the caller groups them and has applied prepare_scan_args.
+hipError_t launch_scan_set(int algo, const ScanArgs& first, const ScanArgs* device_items, uint32_t count, int num_cus,
+                           hipStream_t stream);
 // occurrence positions (extension): appends every s in [a.s_begin, a.s_end) with T[s..s+m) == P to `out`
 // (unordered, at most `cap` entries), total in a.count; the blob must be an EPSM blob
 hipError_t launch_find(const ScanArgs& a, unsigned long long* out, unsigned long long cap, int num_cus,

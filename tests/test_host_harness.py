@@ -77,11 +77,15 @@ def test_smart_report_lines(tmp_path):
     for name in ("HOR", "BM", "KMP", "SO", "BNDM", "EPSM", "SA", "QS", "TUNEDBM", "RAITA", "HASH3", "HASH5", "HASH8", "SBNDM", "KR", "BNDML"):
         line = [ln for ln in out.splitlines() if re.search(r"\] %s \." % name, ln)]
         assert line and "[OK]" in line[0] and "occ 1" in line[0] and "GB/s" in line[0], (name, out)
-        assert re.search(r"\d+\.\d\d \+ \d+\.\d\d ms", line[0])
+        assert re.search(r"\d+\.\d\d+ \+ \d+\.\d\d+ ms", line[0])  # %.2f as the reference above 1 ms, %.4f below
+        assert re.search(r"GB/s\t(hor_scan|bm_scan|kmp_runs|so_runs|bndm_scan|packed_scan|hor_scan_bp|bndml_scan)$", line[0]), line[0]  # the kernel that ran
     table = list((tmp_path / "results").glob("EXP*/rand128.txt"))
     assert table and table[0].read_text().startswith("HOR")
     xml = list((tmp_path / "results").glob("EXP*/rand128.xml"))[0].read_text()
     assert xml.startswith("<RESULTS>") and xml.count("<NAME>") == 16 and "<SEARCH>" in xml and "<BEST>" in xml
+    assert xml.count("<KERNEL>") == 16 and "<KERNEL>kmp_runs</KERNEL>" in xml
+    kernels = list((tmp_path / "results").glob("EXP*/rand128.kernels.txt"))[0].read_text().splitlines()
+    assert len(kernels) == 16 and kernels[0].split() == ["HOR", "hor_scan"] and kernels[2].split() == ["KMP", "kmp_runs"]
     html = list((tmp_path / "results").glob("EXP*/rand128.html"))[0].read_text()
     assert html.startswith("<!DOCTYPE html>") and html.count("<tr><td class=\"algo\">") == 16 and "class=\"best\"" in html
     tex = list((tmp_path / "results").glob("EXP*/rand128.tex"))[0].read_text()

@@ -125,15 +125,16 @@ def test_packed_load_policies(oracle, policy):
         engine.tune(7, 0)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_alternate_serial_kernels(oracle, variant):
     """SO and KMP normally run on the bank-private / full-table runs kernels; the variants kept
     for A/B measurements must give the same counts: 1 = LDS tiles (so_scan, kmp_scan),
     2 = shared-table so_runs and the failure-link kmp_links_runs, 3 = Shift-And in its own AND
-    form (by default it counts in the complemented, Shift-Or form)."""
+    form (by default it counts in the complemented, Shift-Or form) and kmp_runs1 (running maximum, half-line
+    loader), 4 = so_runs1 (a step per byte)."""
     from smart_amd import engine
     engine.tune(6, variant)
-    engine.tune(3, variant)
+    engine.tune(3, min(variant, 3))
     try:
         for r in load_golden("fuzz_vectors.json")["rows"][::2]:
             P, T = fuzz_case(oracle, r)
@@ -468,3 +469,71 @@ def test_occurrence_positions(oracle):
     pos, cnt = smart_amd.find(b"zz", text, cap=4)
     assert cnt == 0 and len(pos) == 0
     text.free()
+
+
+def test_pattern_set_in_one_call(oracle):
+    """smartgpu_search_batch64 / smartgpu_msearch_batch64: the harness loop of smart.c:312-345 as one call —
+    K patterns over one resident text, tables in one arena, launches back to back, one read-back of K counts.
+    Counts must equal the per-call path and the oracle; every algorithm; table sets larger than the staging
+    buffer (KMP: 135 KB per pattern) go up in several copies."""
+    from smart_amd import MultiText
+    n = 1 << 20  # SMART's stock text size (smart.c:416)
+    T = oracle.gen_text(SEED2, 128, 0, n)
+    text = Text.upload(T)
+    rng = np.random.default_rng(11)
+    for m, K in ((32, 40), (2, 9), (8, 17), (300, 5), (4096, 3)):
+        pats = [T[k:k + m].copy() for k in rng.integers(0, n - m, K)]
+        want = [oracle.search("bf", p, T) for p in pats]
+        for a in ALGOS:
+            if not applies(a, m):
+                with pytest.raises(smart_amd.SmartGpuError):
+                    smart_amd.search_batch(a, pats, text)
+                continue
+            counts, pre, run, batch_ms = smart_amd.search_batch(a, pats, text)
+            assert counts.tolist() == want, (a, m, counts.tolist(), want)
+            assert (pre > 0).all() and (run > 0).all() and batch_ms > 0, (a, m)
+            counts2, _, run2, _ = smart_amd.search_batch(a, pats, text, per_pattern_times=False)
+            assert counts2.tolist() == want and run2 is None
+        # a sub-range, as a shard would search it
+        off, nn = 123_457, 500_001
+        sub = [oracle.search("bf", p, T[off:off + nn]) for p in pats]
+        for a in ("hor", "kmp", "so", "epsm"):
+            assert smart_amd.search_batch(a, pats, text, off=off, n=nn)[0].tolist() == sub, (a, m)
+    # 300 KMP patterns: 40 MB of tables through a 32 MB staging buffer; the arena grows once
+    pats = [T[k:k + 32].copy() for k in rng.integers(0, n - 32, 300)]
+    want = [oracle.search("bf", p, T) for p in pats]
+    assert smart_amd.search_batch("kmp", pats, text)[0].tolist() == want
+    assert smart_amd.search_batch("hor", pats, text)[0].tolist() == want
+    with pytest.raises(smart_amd.SmartGpuError):  # one length per set (the harness loops per length)
+        smart_amd.search_batch("hor", [T[:4], T[:5]], text)
+    # several shards, one reduction of the K counts
+    for k in (1, 3):
+        mt = MultiText.upload(T, k, devices=[0] * k)
+        counts, pre, batch_ms = mt.search_batch("bm", pats[:50], reduce="host")
+        assert counts.tolist() == want[:50] and batch_ms > 0, k
+        mt.free()
+    mt = MultiText.upload(T, 1)
+    assert mt.search_batch("so", pats[:20], reduce="rccl")[0].tolist() == want[:20]
+    mt.free()
+    text.free()
+
+
+def test_small_texts_on_the_runs_kernels(oracle):
+    """Texts too small to give every wave 2 KiB runs get shorter runs (kernels.hip balanced_run_len): counts on
+    1 KiB .. 3 MiB texts, every m, sub-ranges that start and end inside runs."""
+    for sigma, n in ((128, 1 << 20), (4, 300_001), (2, 70_000), (128, 1025), (16, 3 << 20)):
+        T = oracle.gen_text(4242 + n, sigma, 0, n)
+        text = Text.upload(T)
+        for m in (1, 2, 3, 16, 29, 30, 33, 64, 254, 255, 256, 1000):
+            if m >= n:
+                continue
+            k = (n // 3) & ~1
+            P = T[k:k + m]
+            want = oracle.search("bf", P, T)
+            got = gpu_counts(P, text, algos=("kmp", "so", "sa"))
+            assert all(v == want for v in got.values()), (sigma, n, m, got, want)
+            off, nn = n // 7 + 3, n // 2 + 1
+            sub = oracle.search("bf", P, T[off:off + nn])
+            got = gpu_counts(P, text, algos=("kmp", "so", "sa"), off=off, n=nn)
+            assert all(v == sub for v in got.values()), (sigma, n, m, got, sub)
+        text.free()
