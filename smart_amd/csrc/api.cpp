@@ -266,29 +266,15 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             for (uint32_t i = 0; i <= m; ++i) tab[i] = static_cast<int16_t>(nx[i]);
             append(tab.data(), tab.size() * 2);
             *halo = m - 1;  // forward halo: the automaton re-scans m-1 bytes
-            {   // transition table of the automaton for P[0..w), 16-byte aligned (kmp_runs)
-                const uint32_t w = std::min<uint32_t>(m, sg::kKmpDfaMaxM);
-                blob.resize((blob.size() + 15) & ~size_t(15), 0);
-                const std::vector<uint8_t> dfa = sg::kmp_dfa(P, w);
-                // State s becomes row id(s) = rotl8(s, 2), the accept state w row 255 (no other state maps
-                // there: rotl8(s, 2) = 255 only for s = 255) — or row 4w while the ids 4s do not wrap (w < 64),
-                // so that short patterns keep a short table; row r is stored XOR-swizzled by r.  Why:
-                // kmp_runs in kernels.hip (LDS bank spread on small alphabets, accept = largest id).
-                const uint32_t acc = w < 64 ? 4 * w : 255u;  // the largest id in use
-                auto id = [w, acc](uint32_t st) { return st == w ? acc : ((st << 2) | (st >> 6)) & 255u; };
-                std::vector<uint8_t> sw(256 * 256, 0);
-                for (uint32_t st = 0; st <= w; ++st) {
-                    const uint32_t r = id(st);
-                    for (uint32_t c = 0; c < 256; ++c) sw[r * 256 + (c ^ r)] = static_cast<uint8_t>(id(dfa[st * 256 + c]));
-                }
-                append(sw.data(), sw.size());
-            }
-            {   // kmp_runs: the same automaton over w = min(m, 254) bytes with an ABSORBING accept row Z.  Every
+            blob.resize((blob.size() + 15) & ~size_t(15), 0);  // the transition table is 16-byte aligned
+            {   // kmp_runs: the automaton over w = min(m, 254) bytes with an ABSORBING accept row Z.  Every
                 // transition into the accept state w leads to Z, Z leads to Z; row id(w) holds the real
                 // delta(w, .).  Z = id(w) + 1 is the largest id in use (the kernel's min(next, id(w)) turns Z
-                // back into the accept state).  Fewer than 63 states: id(s) = 4s, Z = 4w + 1, the table ends
-                // there.  Otherwise id(s) = rotl8(s, 2), id(w) = 254, Z = 255; rotl8 maps only s = 191 to 254
-                // and only s = 255 to 255, so state 191 (if there is one besides w) takes the slot w gave up.
+                // back into the accept state).  Row r is stored XOR-swizzled by r (LDS bank spread on small
+                // alphabets).  Fewer than 63 states: id(s) = 4s, Z = 4w + 1, the table ends there.  Otherwise
+                // id(s) = rotl8(s, 2) — the states a lane is usually in, the low ones, then differ in the bits
+                // that select the bank —, id(w) = 254, Z = 255; rotl8 maps only s = 191 to 254 and only s = 255
+                // to 255, so state 191 (if there is one besides w) takes the slot w gave up.
                 const uint32_t w = std::min<uint32_t>(m, sg::kKmpWindow);
                 const std::vector<uint8_t> dfa = sg::kmp_dfa(P, w);
                 const bool small = w < 63;
@@ -299,7 +285,7 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
                     if (small) return 4 * st;
                     return (st == 191) ? rot(w) : rot(st);
                 };
-                std::vector<uint8_t> sw(256 * 256, 0);
+                std::vector<uint8_t> sw((Z + 1) * 256, 0);
                 for (uint32_t st = 0; st <= w; ++st) {
                     const uint32_t r = id(st);
                     for (uint32_t c = 0; c < 256; ++c) {
@@ -310,6 +296,22 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
                 for (uint32_t c = 0; c < 256; ++c) sw[Z * 256 + (c ^ Z)] = static_cast<uint8_t>(Z);
                 append(sw.data(), sw.size());
             }
+#ifdef SMARTGPU_AB
+            {   // kmp_runs1 (A/B build): the automaton of P[0..w), w = min(m, 255); state s is row id(s) = rotl8(s, 2),
+                // the accept state row 255 — or row 4w while the ids 4s do not wrap (w < 64) —, the largest id (its
+                // running maximum needs that); row r XOR-swizzled by r
+                const uint32_t w = std::min<uint32_t>(m, sg::kKmpDfaMaxM);
+                const std::vector<uint8_t> dfa = sg::kmp_dfa(P, w);
+                const uint32_t acc = w < 64 ? 4 * w : 255u;
+                auto id = [w, acc](uint32_t st) { return st == w ? acc : ((st << 2) | (st >> 6)) & 255u; };
+                std::vector<uint8_t> sw(256 * 256, 0);
+                for (uint32_t st = 0; st <= w; ++st) {
+                    const uint32_t r = id(st);
+                    for (uint32_t c = 0; c < 256; ++c) sw[r * 256 + (c ^ r)] = static_cast<uint8_t>(id(dfa[st * 256 + c]));
+                }
+                append(sw.data(), sw.size());
+            }
+#endif
             break;
         }
         case SMARTGPU_SO: {
@@ -451,7 +453,14 @@ sg::ScanArgs make_args(const smartgpu_plan* p, const smartgpu_text* text, uint64
 
 extern "C" {
 
-const char* smartgpu_version(void) { return "smartgpu 0.1 (gfx950)"; }
+const char* smartgpu_version(void)
+{
+#ifdef SMARTGPU_AB
+    return "smartgpu 0.2 (gfx950, A/B build)";
+#else
+    return "smartgpu 0.2 (gfx950)";
+#endif
+}
 const char* smartgpu_last_error(void) { return g_error.c_str(); }
 
 int smartgpu_device_count(void)
@@ -737,6 +746,10 @@ int smartgpu_probe_read_ms(const smartgpu_text* t, int reps, double* ms_per_pass
 int smartgpu_tune(int key, int value)
 {
     if (key < 0 || key >= 8) { set_error("tune key %d out of range", key); return SMARTGPU_ERR_ARG; }
+    if (!sg::tune_supported(key, value)) {
+        set_error("tune(%d,%d) selects a superseded kernel: only in the A/B build (make -C smart_amd/csrc AB=1 -> libsmartgpu_ab.so)", key, value);
+        return SMARTGPU_ERR_ARG;
+    }
     sg::g_tune[key] = value;
     return SMARTGPU_OK;
 }

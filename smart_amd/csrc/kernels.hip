@@ -14,19 +14,21 @@
 //     tile; a lane verifies right-to-left through the halo by itself and — only for
 //     m-1 > H and only after H+1 bytes matched — parks the window for a
 //     wave-cooperative comparison of the rest (wave_verify).
-//  2. RUNS THROUGH LDS SLABS — the serial automata SO and KMP (so_runs1, kmp_runs1).
-//     A lane owns a run of >= 512 start positions; the wave fetches the next 64 bytes
-//     of each of its 64 runs with four coalesced loads into its own LDS slab and every
-//     lane reads its run back.  No workgroup barrier.
+//  2. RUNS THROUGH LDS SLABS — the serial automata SO and KMP (so_runs, kmp_runs).
+//     A lane owns a run of 2-4 KiB of start positions (128+ bytes on small texts); the wave
+//     fetches the next 128-byte line of each of its 64 runs with coalesced non-temporal loads,
+//     parks it in its own LDS slab one 64-byte half at a time and every lane reads its run
+//     back.  No workgroup barrier after the table set-up.
 //  3. PACKED — EPSM, and the short-pattern / tiny-shift regime of the skip algorithms
 //     (packed_scan): every alignment is compared from registers, no LDS.
 //
 // Restarting an algorithm at a lane / tile / run / GPU boundary preserves the count
 // (SURVEY.md §7 restart table): skip algorithms carry no state between windows, the
 // automata restart in their initial state and re-scan w-1 bytes.  Per-lane hit
-// counters are summed across the 64-lane wave; one 64-bit atomic per wave.
-// so_scan / kmp_scan (LDS tiles for the serial automata) and hor_scan_bp (bank-private
-// LDS layout) are earlier designs kept selectable for A/B runs (smartgpu_tune).
+// counters are summed across the 64-lane wave and the workgroup; one 64-bit atomic per workgroup.
+// A pattern set over a small text runs as ONE grid, gridDim.y = pattern (launch_scan_set).
+// Earlier designs of the serial kernels (so_scan, kmp_scan, so_runs64, so_runs1, kmp_links_runs,
+// kmp_runs1) live in kernels_ab.inc and only in the A/B build (make AB=1, smartgpu_tune).
 #include "kernels.hpp"
 
 #include <map>
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_fi
             while (e < ehi) {
                 // right-to-left comparison (bm.c:83); k = bytes matched
                 uint32_t c = txt[tile_at(e)];
-                const uint32_t c1 = txt[tile_at(e - 1)];  // m = 1 at the tile's first byte: a byte of ptail's padding, unused
+                const uint32_t c1 = txt[tile_at(e - 1)];  // m >= 2 here (launch_scan sends one-byte patterns to the packed matcher)
                 const uint32_t ent = first[c];
                 if (!(ent & 0x8000u)) {  // mismatch on the last byte: bm.c:89 with i = m-1
                     e += ent;
@@ -924,270 +926,9 @@ __global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a1, uint64_t tile
     flush_hits(hits, a.count, smem);
 }
 
-// ---------------------------------------------------------------------------
-// Shift-Or, 32-bit words like the reference  (src/algos/so.c:27-96)
-// Tiles indexed by START position; a lane scans bytes [a, b+w-1) with the state
-// all-ones at a (w = min(m,32)).  L/16 is odd so the lanes' 16-byte LDS reads
-// fall in distinct bank groups.  LDS: u32 S'[257] | text [tile0, tile0+TB+32)
-//
-// The state is kept left-aligned: D' = D << (32-w) and S'[c] = S[c] << (32-w),
-// so the recurrence is unchanged (D' = (D' << 1) | S'[c], so.c:55) and the hit
-// test "D < lim" (so.c:56: bit w-1 of D clear) is the sign test D' >= 0.
-// S'[256] = ~0 << (32-w) is the entry bytes outside the lane's range are mapped
-// to: it keeps the state all-ones, i.e. "not started yet" / "no hit".
-// Per 16-byte chunk the 16 table gathers are issued together (they do not
-// depend on the state), then the recurrence runs on registers.
-// ---------------------------------------------------------------------------
-template <int THREADS, int L, bool LONG>  // LONG: m > 32, prefix hits are verified
-__global__ __launch_bounds__(THREADS) void so_scan(ScanArgs a1, uint64_t tile_first,
-                                                   uint32_t ntiles, const ScanArgs* __restrict__ batch)
-{
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
-    constexpr int TB = THREADS * L;
-    static_assert((L / 16) % 2 == 1, "L/16 must be odd (LDS bank spread)");
-    static_assert(L % 16 == 0 && TB % (THREADS * 16) == 0, "whole 16-byte rows");
-    constexpr int N = TB / (THREADS * 16);
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t m = a.m, w = m < 32 ? m : 32;
-    uint32_t* S = reinterpret_cast<uint32_t*>(smem);  // 257 entries, padded to 1040 B
-    uint8_t* txt = smem + 1040;
-
-    for (uint32_t i = threadIdx.x; i < 257; i += THREADS)
-        S[i] = (i < 256 ? reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] : 0xFFFFFFFFu)
-               << (32 - w);  // low 32-w bits stay zero, so nothing shifts up into the state
-
-    uint32_t hits = 0;
-    const uint64_t t_end = tile_first + ntiles;
-    static_assert(N == 5, "prefetch registers are written out for L = 80");
-    uint4 p0, p1, p2, p3, p4, ph;  // prefetch registers: 5 tile rows + 32 bytes of forward halo
-    const bool halo_lane = threadIdx.x < 2;
-    auto issue = [&](uint64_t tile0) {
-        const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
-        p0 = ld_stream16(src);
-        p1 = ld_stream16(src + THREADS * 16);
-        p2 = ld_stream16(src + THREADS * 32);
-        p3 = ld_stream16(src + THREADS * 48);
-        p4 = ld_stream16(src + THREADS * 64);
-        if (halo_lane) ph = ld_stream16(src + TB);
-    };
-    uint64_t t = tile_first + blockIdx.x;
-    issue(t * TB);
-    for (; t < t_end; t += gridDim.x) {
-        const uint64_t tile0 = t * TB;
-        __syncthreads();
-        {
-            uint8_t* dst = txt + threadIdx.x * 16u;
-            *reinterpret_cast<uint4*>(dst) = p0;
-            *reinterpret_cast<uint4*>(dst + THREADS * 16) = p1;
-            *reinterpret_cast<uint4*>(dst + THREADS * 32) = p2;
-            *reinterpret_cast<uint4*>(dst + THREADS * 48) = p3;
-            *reinterpret_cast<uint4*>(dst + THREADS * 64) = p4;
-            if (halo_lane) *reinterpret_cast<uint4*>(dst + TB) = ph;
-        }
-        __syncthreads();
-        if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
-
-        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
-        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
-        const uint64_t sb = seg + L < a.s_end ? seg + L : a.s_end;
-        bool parked = false;  // first candidate of this tile awaiting wave_verify
-        const uint8_t* parked_at = a.text;
-        if (sa < sb) {
-            const uint32_t j0 = (uint32_t)(sa - tile0);
-            const uint32_t jend = (uint32_t)(sb - tile0) + w - 1;
-            uint32_t D = 0xFFFFFFFFu << (32 - w);
-            for (uint32_t base = j0 & ~15u; base < jend; base += 16) {
-                const uint4 v = *reinterpret_cast<const uint4*>(txt + base);
-                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-                // bytes of this chunk inside [j0, jend): all of them except at the two ends
-                const bool full = base >= j0 && base + 16 <= jend;
-                uint32_t sv[16];
-                if (full) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) sv[q] = S[(d[q >> 2] >> (8 * (q & 3))) & 0xFFu];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const uint32_t j = base + q;
-                        const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
-                        sv[q] = S[(j >= j0 && j < jend) ? c : 256u];
-                    }
-                }
-                // recurrence on registers; the sign bit of D after byte q is the "no hit"
-                // flag and is shifted into H with one v_alignbit (bit 15-q of H <-> byte q)
-                uint32_t H = 0xFFFFFFFFu;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    D = (D << 1) | sv[q];                        // so.c:55
-                    H = __builtin_amdgcn_alignbit(H, D, 31);     // H = (H << 1) | (D >> 31); so.c:56
-                }
-                uint32_t hm = ~H & 0xFFFFu;
-                if (!LONG) {
-                    hits += __popc(hm);
-                } else {
-                    while (hm) {  // 32-byte prefix matched, ending at byte q: verify P[32..m)
-                        const uint32_t bit = 31u - __builtin_clz(hm);
-                        hm &= ~(1u << bit);
-                        const uint32_t q = 15u - bit;
-                        const uint8_t* rest = a.text + tile0 + base + q + 1;  // = text + h + w
-                        if (!parked) {
-                            parked = true;
-                            parked_at = rest;
-                        } else {
-                            hits += global_equal(rest, a.blob + w, m - w);
-                        }
-                    }
-                }
-            }
-        }
-        if (LONG) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
-    }
-    flush_hits(hits, a.count, smem);
-}
-
-// ---------------------------------------------------------------------------
-// Knuth-Morris-Pratt  (reference: src/algos/kmp.c:27-68)
-// Tiles indexed by START position, forward halo m-1.  A lane restarts in state 0
-// at its first start position and scans m-1 bytes into the next lane's run
-// (SURVEY.md §7 restart table), so the run length L is picked from m on the
-// host (launch_scan) to bound that re-scan.  Lanes read their runs from LDS in
-// 16-byte chunks (L/16 odd => distinct bank groups).  Used for m <= 40; longer
-// patterns need longer runs than LDS tiles allow and go to kmp_stream below.
-// LDS: u32 tab[m] | text [tile0, tile0+TB+halo)
-// State 0 (by far the most common on large alphabets) is handled in registers:
-// next[0] = -1, so the step is st = (c == P[0]) (kmp.c:57-60).
-// ---------------------------------------------------------------------------
-// One 16-byte chunk of the automaton.  tab[i] = P[i] << 16 | (uint16)next[i], so a
-// state costs one LDS read.  The branch into the table-driven step is taken per
-// WAVE (ballot): on large alphabets most steps find every lane in state 0 and
-// cost four VALU instructions.
-template <bool CHECK>
-__device__ __forceinline__ void kmp_chunk(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
-                                          int& st, uint32_t& hits, int m, uint32_t p0, int next_m,
-                                          const uint32_t* __restrict__ tab)
-{
-    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
-        bool live = true;
-        if (CHECK) {
-            const uint32_t j = j_base + q;
-            live = j >= j0 && j < jend;
-        }
-        const bool slow = live && st != 0;
-        int st_new = (c == p0) ? 1 : 0;  // from state 0: next[0] = -1, then ++ (kmp.c:57-60)
-        if (m == 1 && live && st_new) {  // a one-byte pattern is complete here (kmp.c:61-64)
-            ++hits;
-            st_new = next_m;
-        }
-        if (__any(slow)) {
-            if (slow) {
-                int s2 = st;
-                uint32_t e = tab[s2];
-                while ((e >> 16) != c) {       // kmp.c:57-58
-                    s2 = (int16_t)(e & 0xFFFFu);
-                    if (s2 < 0) break;
-                    e = tab[s2];
-                }
-                ++s2;
-                if (s2 >= m) {                 // kmp.c:61-64
-                    ++hits;
-                    s2 = next_m;
-                }
-                st_new = s2;
-            }
-        }
-        st = live ? st_new : st;
-    }
-}
-
-template <int THREADS, int L>
-__global__ __launch_bounds__(THREADS) void kmp_scan(ScanArgs a1, uint64_t tile_first,
-                                                    uint32_t ntiles, const ScanArgs* __restrict__ batch)
-{
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
-    constexpr int TB = THREADS * L;
-    static_assert((L / 16) % 2 == 1, "L/16 must be odd (LDS bank spread)");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int m = (int)a.m;
-    const uint32_t FH16 = round16(a.halo);  // forward halo, a.halo = m-1
-    uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
-    uint8_t* txt = smem + round16(4 * m);
-    const int16_t* gnext = reinterpret_cast<const int16_t*>(a.blob + kTableOff);
-    for (uint32_t i = threadIdx.x; i < (uint32_t)m; i += THREADS)
-        tab[i] = ((uint32_t)a.blob[i] << 16) | (uint16_t)gnext[i];
-    const uint32_t p0 = a.blob[0];
-    const int next_m = gnext[m];
-
-    uint32_t hits = 0;
-    for (uint64_t t = tile_first + blockIdx.x; t < tile_first + ntiles; t += gridDim.x) {
-        const uint64_t tile0 = t * TB;
-        __syncthreads();
-        stage_tile<THREADS, TB>(txt, a.text + tile0);
-        stage_bytes<THREADS>(txt + TB, a.text + tile0 + TB, FH16);
-        __syncthreads();
-        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
-        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
-        const uint64_t sb = seg + L < a.s_end ? seg + L : a.s_end;
-        if (sa >= sb) continue;
-        // bytes [sa, sb+m-1) of the tile, as LDS offsets
-        const uint32_t j0 = (uint32_t)(sa - tile0);
-        const uint32_t jend = (uint32_t)(sb - tile0) + (uint32_t)m - 1;
-        uint32_t j = j0 & ~15u;
-        if (m == 1) {  // no automaton: count the bytes equal to P[0]
-            for (; j < jend; j += 16) {
-                const uint4 v = *reinterpret_cast<const uint4*>(txt + j);
-                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
-                    hits += (c == p0) && (j + q >= j0) && (j + q < jend);
-                }
-            }
-            continue;
-        }
-        int st = 0;
-        // head chunk (may start inside it), full chunks, tail chunk
-        if (j < j0 || j + 16 > jend) {
-            kmp_chunk<true>(*reinterpret_cast<const uint4*>(txt + j), j, j0, jend, st, hits, m, p0, next_m, tab);
-            j += 16;
-        }
-        for (; j + 16 <= jend; j += 16)
-            kmp_chunk<false>(*reinterpret_cast<const uint4*>(txt + j), j, j0, jend, st, hits, m, p0, next_m, tab);
-        if (j < jend)
-            kmp_chunk<true>(*reinterpret_cast<const uint4*>(txt + j), j, j0, jend, st, hits, m, p0, next_m, tab);
-    }
-    flush_hits(hits, a.count, smem);
-}
-
-// KMP over per-lane RUNS streamed through LDS.  A lane owns a run of `run_len` start
-// positions (any length: the host picks it from m so that the re-scan of m-1 bytes is
-// bounded), but a lane-private stream is a terrible access pattern (64 lanes x 16 B from 64
-// different lines per wave-load: 1.1 TB/s measured even with no automaton work).
-// So the WAVE moves the data: per step it fetches the next 64 bytes of each of its
-// 64 runs with four coalesced wave-loads (4 lanes cover one run's 64-byte sector),
-// parks them in its own LDS slab [run][80 B] (stride 5*16 B: odd, so the lanes'
-// ds_read_b128 hit distinct bank groups) and each lane then reads its run's 64
-// bytes back.  No workgroup barrier: a wave's DS operations execute in order.
-// The next step's loads are issued before the current step is processed.
-//
-// kmp_runs1: the failure function (kmp.c:27-41) is expanded on the host into the automaton's
-// transition table delta[s][c] (u8, 256 columns, (w+1)*256 B at LDS offset 0, w = min(m,255)),
-// so a text byte costs ONE dependent LDS lookup and no data-dependent loop: st = delta[st][c].
-// The address st*256 + c is ONE v_perm_b32 (byte 1 = state, byte 0 = text byte).  The accept
-// state w is the largest state id, so "did an occurrence end in these 64 bytes" is a running
-// maximum (v_max3_u32: half an op per byte); only a lane that saw one walks its 64 bytes again,
-// counting.  One 1024-thread workgroup per CU shares the table (64 KB at m >= 255).
-// kmp_links_runs: the failure links themselves (kmp_chunk above), for A/B.
-constexpr int kRunSlab = 64 * 80;  // LDS bytes per wave
-
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
 
-// MASK: instead of counting, return the chunk's hits as a bit mask in `hits` (bit q = the
-// automaton reached state w at byte q) — the long-pattern mode, where a hit is only a
-// 255-byte prefix match that still has to be verified.
 // delta[st][c]: one v_perm_b32 builds st*256 + c; the row of state st is stored XOR-swizzled,
 // delta[st][c] at st*256 + (c ^ st), which costs one v_xor: every row starts on LDS bank 0, so on
 // a small alphabet (few distinct c) lanes in different states would all meet on the same few
@@ -1196,51 +937,6 @@ __device__ __forceinline__ uint32_t kmp_delta(uint32_t dword, uint32_t st, int b
 {
     const uint32_t addr = __builtin_amdgcn_perm(dword, st, 0x0c0c0004u + byte) ^ st;
     return *(const lds_u8_t*)(size_t)addr;
-}
-
-template <bool CHECK, bool MASK>
-__device__ __forceinline__ void kmp_dfa_chunk(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
-                                              uint32_t& st, uint32_t& hits, uint32_t w)
-{
-    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const uint32_t nx = kmp_delta(d[q >> 2], st, q & 3);
-        if (CHECK) {
-            const uint32_t j = j_base + q;
-            const bool live = j >= j0 && j < jend;
-            st = live ? nx : st;
-            if (MASK) hits |= (live && nx == w) ? (1u << q) : 0u;
-            else hits += live && nx == w;
-        } else {
-            st = nx;
-            if (MASK) hits |= (nx == w) ? (1u << q) : 0u;
-            else hits += nx == w;
-        }
-    }
-}
-
-// max(a, b, c) as one v_max3_u32 the optimiser cannot reassociate: written with max(), the 64
-// running-maximum steps of a run become a tree evaluated at the END of the step and all 64
-// states stay live (165 VGPRs, spills reloaded inside the loop).
-__device__ __forceinline__ uint32_t max3_now(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t r;
-    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// The common case: 16 transitions, running maximum of the states (no hit bookkeeping).
-__device__ __forceinline__ void kmp_dfa_chunk_max(const uint4& v, uint32_t& st, uint32_t& mx)
-{
-    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 16; q += 2) {
-        const uint32_t s1 = kmp_delta(d[q >> 2], st, q & 3);
-        const uint32_t s2 = kmp_delta(d[q >> 2], s1, (q + 1) & 3);
-        st = s2;
-        mx = max3_now(mx, s1, s2);
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1268,6 +964,16 @@ __device__ __forceinline__ void kmp_dfa_chunk_max(const uint4& v, uint32_t& st, 
 constexpr uint32_t kRunLine = 128;       // bytes of a run fetched per step
 constexpr int kLineSlab = 64 * 64;       // LDS bytes per wave
 constexpr int kRunWaves = 16;            // one 1024-thread workgroup per CU shares the table
+
+// Which group of runs a wave starts with (it then strides by the number of waves in the grid).  A text that
+// gives every wave of the grid a group: the waves of a workgroup take ADJACENT groups — one contiguous stretch
+// of the text per CU (measured: 5-10 % faster than groups a grid apart, whose pages miss the CU's TLB).  A
+// small text: the groups go to different CUs first, one wave per CU working before a second one does.
+__device__ __forceinline__ uint64_t first_group(uint64_t nruns, uint32_t per_group, uint32_t waves, uint32_t wave)
+{
+    const uint64_t ngroups = (nruns + per_group - 1) / per_group;
+    return ngroups >= (uint64_t)gridDim.x * waves ? (uint64_t)blockIdx.x * waves + wave : blockIdx.x + (uint64_t)gridDim.x * wave;
+}
 
 struct RunIo {
     uint8_t* wr;         // where this lane parks its piece of load i (+ 1024*i)
@@ -1314,46 +1020,6 @@ __device__ __forceinline__ uint4 run_piece(const RunIo& io, int c)
         *reinterpret_cast<uint4*>((io_).wr + 3072) = r3_;                          \
     } while (0)
 
-// ---- the whole-line loader (so_runs1) ----------------------------------------------------------
-// Load i (0..7) fetches the whole 128-byte lines of runs 8i .. 8i+7, lane = 8*(run in block) + piece:
-// eight lanes per line and every line requested by ONE instruction, so the loads can be non-temporal
-// like the tile kernels' (a streaming read runs at 7.0-7.1 TB/s with nt loads, 6.2-6.3 TB/s without —
-// and 6.05 TB/s = 75.6 % is what the half-line loader above reaches with the automaton compiled out,
-// whatever the run length, 128 bytes = fully contiguous wave-loads to 4096: its ceiling is the cache
-// policy, not the access pattern; there every line is touched by two instructions and the second has
-// to find it in cache).  Parking then stores with half the lanes per half (16 ds_write_b128 per line
-// instead of 8).  so_runs1: 63-67 % -> 71-72 %.  kmp_runs1, bound by its dependent lookups rather than
-// by the data path, lost 3 points to the extra stores and keeps the half-line loader.
-struct LineIo {
-    uint8_t* wr_e;       // where this lane parks its piece of an even-numbered load (+ 512*i)
-    uint8_t* wr_o;       // ... of an odd-numbered load
-    bool first_half;     // loader role: this lane's piece belongs to bytes 0..63 of the line
-    const uint8_t* rd;   // this lane's own run in the slab
-    uint32_t rswz;       // XOR applied to the piece offset 16*c when reading
-    uint32_t loff;       // loader role: byte offset of this lane's piece inside an 8-run block
-};
-
-__device__ __forceinline__ LineIo line_io(uint8_t* slab, uint32_t lane, uint32_t run_len)
-{
-    LineIo io;
-    const uint32_t c = lane & 7u, rb = lane >> 3;  // piece of the line, run inside the block
-    // slot of piece q (0..3 of the half) of run R: 4R + (q ^ ((R >> 2) & 3)); R = 8i + rb gives
-    // (R >> 2) & 3 = ((i & 1) << 1) | (rb >> 2)
-    const uint32_t q = c & 3u, t = rb >> 2;
-    io.wr_e = slab + (4u * rb + (q ^ t)) * 16u;
-    io.wr_o = slab + (4u * rb + (q ^ t ^ 2u)) * 16u;
-    io.first_half = c < 4u;
-    io.rd = slab + 64u * lane;
-    io.rswz = 16u * ((lane >> 2) & 3u);
-    io.loff = rb * run_len + 16u * c;
-    return io;
-}
-
-__device__ __forceinline__ uint4 run_piece(const LineIo& io, int c)
-{
-    return *reinterpret_cast<const uint4*>(io.rd + ((16u * c) ^ io.rswz));
-}
-
 #define LINE_FETCH(gbase_, blk_, off_)                                             \
     do {                                                                           \
         const uint8_t* p_ = (gbase_) + (off_);                                     \
@@ -1366,423 +1032,6 @@ __device__ __forceinline__ uint4 run_piece(const LineIo& io, int c)
         n6 = ld_stream16(p_ + (blk_)[6]);                                          \
         n7 = ld_stream16(p_ + (blk_)[7]);                                          \
     } while (0)
-// the same in two instalments (swap loader): the registers of the first halves are free again after the
-// first park of a line, those of the second halves after the second
-#define LINE_FETCH_EVEN(gbase_, blk_, off_)                                        \
-    do {                                                                           \
-        const uint8_t* p_ = (gbase_) + (off_);                                     \
-        n0 = ld_stream16(p_ + (blk_)[0]);                                          \
-        n2 = ld_stream16(p_ + (blk_)[2]);                                          \
-        n4 = ld_stream16(p_ + (blk_)[4]);                                          \
-        n6 = ld_stream16(p_ + (blk_)[6]);                                          \
-    } while (0)
-#define LINE_FETCH_ODD(gbase_, blk_, off_)                                         \
-    do {                                                                           \
-        const uint8_t* p_ = (gbase_) + (off_);                                     \
-        n1 = ld_stream16(p_ + (blk_)[1]);                                          \
-        n3 = ld_stream16(p_ + (blk_)[3]);                                          \
-        n5 = ld_stream16(p_ + (blk_)[5]);                                          \
-        n7 = ld_stream16(p_ + (blk_)[7]);                                          \
-    } while (0)
-// park one 64-byte half of every run's line: the lanes holding pieces of that half store, the others idle
-#define LINE_PARK(io_, first_)                                                     \
-    do {                                                                           \
-        if ((io_).first_half == (first_)) {                                        \
-            *reinterpret_cast<uint4*>((io_).wr_e) = n0;                            \
-            *reinterpret_cast<uint4*>((io_).wr_o + 512) = n1;                      \
-            *reinterpret_cast<uint4*>((io_).wr_e + 1024) = n2;                     \
-            *reinterpret_cast<uint4*>((io_).wr_o + 1536) = n3;                     \
-            *reinterpret_cast<uint4*>((io_).wr_e + 2048) = n4;                     \
-            *reinterpret_cast<uint4*>((io_).wr_o + 2560) = n5;                     \
-            *reinterpret_cast<uint4*>((io_).wr_e + 3072) = n6;                     \
-            *reinterpret_cast<uint4*>((io_).wr_o + 3584) = n7;                     \
-        }                                                                          \
-    } while (0)
-
-template <bool PREFIX>  // PREFIX: m > 255 — the automaton of the 255-byte prefix; hits are verified
-__global__ __launch_bounds__(kRunWaves * 64) void kmp_runs1(ScanArgs a1, uint32_t run_len, uint64_t nruns,
-                                                       uint32_t dfa_off, const ScanArgs* __restrict__ batch)
-{
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t m = a.m;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t w = PREFIX ? kKmpDfaMaxM : m;  // length the automaton recognises
-    // States are renumbered on the host (api.cpp build_blob): state s is row rotl8(s, 2), the accept state
-    // row 255 (row 4w when there are fewer than 64 states) — the largest id, which the running maximum needs.  A row's entries are XOR-swizzled by the
-    // row id, so a lookup's LDS bank is ((c ^ id) >> 2) & 31: with ids 0, 4, 8, ... the states a lane is
-    // usually in (the low ones) sit on different banks even when c is one of two values.  Numbered 0..w
-    // they shared banks 0 and 1 there (rand2: 49-53 % of 8 TB/s, rand4: 55-60 %).
-    const uint32_t acc = w < 64 ? 4 * w : 255u;  // ids 0, 4, .., 4(w-1) do not wrap below 64 states: the table ends there
-    const uint32_t table_bytes = (acc + 1) * 256;
-    const RunIo io = run_io(smem + table_bytes + wave * kLineSlab, lane, run_len);
-    {
-        const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
-        uint4* t = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = threadIdx.x; i < table_bytes / 16; i += kRunWaves * 64) t[i] = g[i];
-    }
-    // the perm result IS the LDS address: the table sits at LDS offset 0 (no static LDS in
-    // this kernel, so the dynamic segment starts there); a poisoned count if that ever changes
-    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {
-        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
-        return;
-    }
-    __syncthreads();  // the only workgroup barrier: table visible
-
-    uint32_t hits = 0;
-    const uint64_t run_first = a.s_begin / run_len;  // runs are cut on absolute offsets
-    const uint64_t nwaves = (uint64_t)gridDim.x * kRunWaves;
-    const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
-    // group = 64 consecutive runs handled by one wave
-    for (uint64_t g = blockIdx.x + (uint64_t)gridDim.x * wave; g * 64 < nruns; g += nwaves) {
-        // loader addresses = wave-uniform base of the group + wave-uniform offset of the 16-run
-        // block i + ONE per-lane offset.  A block that lies entirely past the last run re-reads
-        // block 0 (loaded, never consumed); the lanes of the one block that straddles the end
-        // read at most 15 runs past it, inside the text's back pad (run_len <= 8192).
-        const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
-        uint32_t blk[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) blk[i] = g * 64 + 16 * i < nruns ? 16u * i * run_len : 0u;
-        // owner role: this lane's run and the bytes of it that count
-        const uint64_t my = g * 64 + lane;
-        const uint64_t seg = (run_first + my) * run_len;
-        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
-        const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
-        const bool owner = my < nruns && sa < sb;
-        const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
-        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
-
-        uint4 n0, n1, n2, n3, n4, n5, n6, n7;
-        RUN_FETCH(gbase, blk, 0u);
-        uint32_t st = 0;
-        bool dense = false;   // wave-uniform: the last whole step reached the accept state
-        bool parked = false;  // PREFIX: first unverified prefix hit of this step
-        const uint8_t* parked_at = a.text;
-        // one 64-byte half of a line: the bytes [jb, jb + 64) of every run are in the slab
-        auto half = [&](const uint32_t jb) {
-            // one 16-byte chunk with hit bookkeeping (run boundaries, and steps that reach state w);
-            // returns whether the accept state was seen
-            auto careful = [&](int q, bool whole) -> bool {
-                const uint4 v = run_piece(io, q);
-                const uint32_t j = jb + 16u * q;
-                if (!PREFIX) {
-                    const uint32_t h0 = hits;
-                    if (whole) kmp_dfa_chunk<false, false>(v, j, j0, jend, st, hits, acc);
-                    else if (j < jend && j + 16 > j0) kmp_dfa_chunk<true, false>(v, j, j0, jend, st, hits, acc);
-                    return hits != h0;
-                } else {
-                    uint32_t hm = 0;
-                    if (whole) kmp_dfa_chunk<false, true>(v, j, j0, jend, st, hm, acc);
-                    else if (j < jend && j + 16 > j0) kmp_dfa_chunk<true, true>(v, j, j0, jend, st, hm, acc);
-                    const bool seen = hm != 0;
-                    while (hm) {  // the prefix ends at byte j+b: verify P[255..m)
-                        const uint32_t b = __builtin_ctz(hm);
-                        hm &= hm - 1;
-                        const uint8_t* rest = a.text + seg + j + b + 1;  // = text + start + w
-                        if (!parked) {
-                            parked = true;
-                            parked_at = rest;
-                        } else {
-                            hits += global_equal(rest, a.blob + w, m - w);
-                        }
-                    }
-                    return seen;
-                }
-            };
-            if (jb >= j0 && jb + 64u <= jend) {  // the whole half is inside the run
-                bool seen = false;
-                if (!dense) {
-                    uint32_t at[5], mx[4];  // state before each 16-byte chunk, running maximum inside it
-                    at[0] = st;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        mx[q] = 0;
-                        kmp_dfa_chunk_max(run_piece(io, q), st, mx[q]);
-                        at[q + 1] = st;
-                    }
-                    // chunks that reached the accept state are walked again, counting (one copy of
-                    // that code: the chunk index is a run-time value)
-                    uint32_t todo = (mx[0] == acc ? 1u : 0u) | (mx[1] == acc ? 2u : 0u) | (mx[2] == acc ? 4u : 0u) | (mx[3] == acc ? 8u : 0u);
-                    seen = todo != 0;
-#pragma unroll 1
-                    while (todo) {
-                        const int q = __builtin_ctz(todo);
-                        todo &= todo - 1;
-                        st = q == 0 ? at[0] : q == 1 ? at[1] : q == 2 ? at[2] : at[3];
-                        careful(q, true);
-                    }
-                    st = at[4];
-                } else {
-#pragma unroll 1
-                    for (int q = 0; q < 4; ++q) seen |= careful(q, true);
-                }
-                // where occurrences are frequent (short patterns, small alphabets) walking twice
-                // costs more than it saves: the wave counts directly while an eighth of its lanes
-                // saw one in the last half
-                dense = __popcll(__ballot(seen)) >= 8;
-            } else {
-#pragma unroll 1
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t j = jb + 16u * q;
-                    careful(q, j >= j0 && j + 16 <= jend);
-                }
-            }
-            if (PREFIX && __any(parked)) {  // wave-uniform point: at most one parked hit per lane
-                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
-                parked = false;
-            }
-        };
-        for (uint32_t k = 0; k < nlines; ++k) {
-            RUN_PARK(io, n0, n1, n2, n3);
-            half(k * kRunLine);
-            RUN_PARK(io, n4, n5, n6, n7);
-            if (k + 1 < nlines) RUN_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
-            half(k * kRunLine + 64u);
-        }
-    }
-    flush_hits(hits, a.count, smem);
-}
-
-// The failure links followed per byte (the reference's loop, kmp.c:55-66), A/B only: smartgpu_tune(3,2).
-__global__ __launch_bounds__(256) void kmp_links_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
-                                                uint32_t, const ScanArgs* __restrict__ batch)
-{
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t m = a.m;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    // LDS: [table][4 wave slabs]
-    const uint32_t w = m;
-    const uint32_t table_bytes = round16(4 * m);
-    uint8_t* slab = smem + table_bytes + wave * kRunSlab;
-    const int16_t* gnext = reinterpret_cast<const int16_t*>(a.blob + kTableOff);
-    {
-        uint32_t* tab = reinterpret_cast<uint32_t*>(smem);
-        for (uint32_t i = threadIdx.x; i < m; i += 256)
-            tab[i] = ((uint32_t)a.blob[i] << 16) | (uint16_t)gnext[i];
-    }
-    __syncthreads();  // the only workgroup barrier: tables visible
-    const uint32_t* tab = reinterpret_cast<const uint32_t*>(smem);
-    const uint32_t p0 = a.blob[0];
-    const int next_m = gnext[m];
-
-    uint32_t hits = 0;
-    const uint64_t run_first = a.s_begin / run_len;  // runs are cut on absolute offsets
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-    const uint32_t span = run_len + w - 1;           // bytes a run scans
-    const uint32_t nsteps = (span + 63) / 64;
-    // group = 64 consecutive runs handled by one wave
-    for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g * 64 < nruns; g += nwaves) {
-        // loader role: lane covers piece (lane & 3) of runs 16*i + (lane >> 2), i = 0..3
-        const uint8_t* src[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint64_t r = g * 64 + 16 * i + (lane >> 2);
-            if (r >= nruns) r = nruns - 1;  // clamp: loaded but never consumed
-            src[i] = a.text + (run_first + r) * run_len + (lane & 3u) * 16u;
-        }
-        // owner role: this lane's run and the bytes of it that count
-        const uint64_t my = g * 64 + lane;
-        const uint64_t seg = (run_first + my) * run_len;
-        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
-        const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
-        const bool owner = my < nruns && sa < sb;
-        const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
-        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
-
-        uint4 nx0 = *reinterpret_cast<const uint4*>(src[0]);
-        uint4 nx1 = *reinterpret_cast<const uint4*>(src[1]);
-        uint4 nx2 = *reinterpret_cast<const uint4*>(src[2]);
-        uint4 nx3 = *reinterpret_cast<const uint4*>(src[3]);
-        int sti = 0;
-        for (uint32_t k = 0; k < nsteps; ++k) {
-            // park this step's 64 bytes of every run in the slab
-            {
-                uint8_t* dst = slab + (lane >> 2) * 80u + (lane & 3u) * 16u;
-                *reinterpret_cast<uint4*>(dst) = nx0;
-                *reinterpret_cast<uint4*>(dst + 16 * 80) = nx1;
-                *reinterpret_cast<uint4*>(dst + 32 * 80) = nx2;
-                *reinterpret_cast<uint4*>(dst + 48 * 80) = nx3;
-            }
-            if (k + 1 < nsteps) {  // prefetch the next step (wave-uniform)
-                const uint32_t o = (k + 1) * 64u;
-                nx0 = *reinterpret_cast<const uint4*>(src[0] + o);
-                nx1 = *reinterpret_cast<const uint4*>(src[1] + o);
-                nx2 = *reinterpret_cast<const uint4*>(src[2] + o);
-                nx3 = *reinterpret_cast<const uint4*>(src[3] + o);
-            }
-            const uint32_t jb = k * 64u;
-            const uint8_t* mine = slab + lane * 80u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 v = *reinterpret_cast<const uint4*>(mine + 16 * q);
-                const uint32_t j = jb + 16u * q;
-                const bool full = j >= j0 && j + 16 <= jend;
-                {
-                    if (full) kmp_chunk<false>(v, j, j0, jend, sti, hits, (int)m, p0, next_m, tab);
-                    else if (j < jend && j + 16 > j0) kmp_chunk<true>(v, j, j0, jend, sti, hits, (int)m, p0, next_m, tab);
-                }
-            }
-        }
-    }
-    flush_hits(hits, a.count, smem);
-}
-
-// Shift-Or over per-lane RUNS (the structure of kmp_runs1 above).  With LDS tiles a lane's run is
-// 80 bytes and the w-1 bytes it re-scans to rebuild the state cost up to 39 % extra work per
-// owned byte; runs of 2-4 KiB make that 1 %.  Same recurrence as so_scan.
-//
-// The S' table is BANK-PRIVATE: u32 S'[256][64], entry c of lane l at byte c*256 + l*4, i.e.
-// always in bank l (ds_read_b32 banks are (a/4) mod 32 over two 32-lane groups).  A gather of
-// 64 different bytes is then conflict-free by construction (a shared 1 KB table: 3x conflicts on
-// rand128, LDS 80 % busy — PMC), and the address is ONE v_perm_b32 (byte 1 = text byte, byte 0 =
-// 4*lane).  64 KB table + 16 slabs of 4 KB = one 1024-thread workgroup per CU.
-// so_runs64 (A/B, smartgpu_tune(6,2)): the first runs kernel — shared table, 64-byte steps.
-// AND = true: Shift-And (sa.c:36-94), the dual recurrence on the same machinery: a SET bit means
-// "a prefix of that length ends here", D = ((D << 1) | 1) & S[c], hit <=> bit w-1 set.  Left-
-// aligned like SO: the 1 enters at bit 32-w, the hit is the sign bit, bytes outside a lane's
-// range map to the mask 0 (no prefix survives).
-template <bool LONG, bool AND>  // LONG: m > 32, hits of the 32-byte prefix are verified
-__global__ __launch_bounds__(kRunWaves * 64) void so_runs1(ScanArgs a1, uint32_t run_len, uint64_t nruns, const ScanArgs* __restrict__ batch)
-{
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t m = a.m, w = m < 32 ? m : 32;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* S = reinterpret_cast<uint32_t*>(smem);
-    const LineIo io = line_io(smem + 65536 + wave * kLineSlab, lane, run_len);
-    const uint32_t sentinel = AND ? 0u : 0xFFFFFFFFu << (32 - w);  // mask of a byte outside the lane's range
-    const uint32_t one = 1u << (32 - w);                          // AND: the bit shifted in
-    const uint32_t hinit = AND ? 0u : 0xFFFFFFFFu;                 // hit collector before any hit
-    {   // expand the 256 masks to one copy per lane through a 1 KB staging area (wave 0's slab):
-        // one global load per thread instead of 16 dependent broadcast loads
-        uint32_t* stage = reinterpret_cast<uint32_t*>(smem + 65536);
-        if (threadIdx.x < 256) stage[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.blob + a.so_off)[threadIdx.x] << (32 - w);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < 256 * 64; i += kRunWaves * 64) S[i] = stage[i >> 6];
-    }
-    // the perm result IS the LDS address: the table sits at LDS offset 0 (this kernel has no
-    // static LDS, so the dynamic segment starts there); a poisoned count if that ever changes
-    const uint32_t lane4 = lane * 4u;
-    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {
-        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
-        return;
-    }
-    __syncthreads();  // the only workgroup barrier: table visible
-
-    uint32_t hits = 0;
-    const uint64_t run_first = a.s_begin / run_len;
-    const uint64_t nwaves = (uint64_t)gridDim.x * kRunWaves;
-    const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
-    for (uint64_t g = blockIdx.x + (uint64_t)gridDim.x * wave; g * 64 < nruns; g += nwaves) {
-        const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
-        uint32_t blk[8];  // a block that lies entirely past the last run re-reads block 0 (loaded, never consumed)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) blk[i] = g * 64 + 8 * i < nruns ? 8u * i * run_len : 0u;
-        const uint64_t my = g * 64 + lane;
-        const uint64_t seg = (run_first + my) * run_len;
-        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
-        const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
-        const bool owner = my < nruns && sa < sb;
-        const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
-        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
-
-        uint4 n0, n1, n2, n3, n4, n5, n6, n7;
-        LINE_FETCH(gbase, blk, 0u);
-        uint32_t D = sentinel;  // SO: all ones, SA: zero — no prefix matched yet
-        bool parked = false;
-        const uint8_t* parked_at = a.text;
-        // one 64-byte half of a line: the bytes [jb, jb + 64) of every run are in the slab
-        auto half = [&](const uint32_t jb) {
-            // hit mask of one 16-byte chunk (bit 15-q: a window ends at byte q)
-            auto take_hits = [&](uint32_t base, uint32_t hm) {
-                if (!LONG) {
-                    hits += __popc(hm);
-                } else {
-                    while (hm) {  // 32-byte prefix matched, ending at byte q: verify P[32..m)
-                        const uint32_t bit = 31u - __builtin_clz(hm);
-                        hm &= ~(1u << bit);
-                        const uint8_t* rest = a.text + seg + base + (15u - bit) + 1;
-                        if (!parked) {
-                            parked = true;
-                            parked_at = rest;
-                        } else {
-                            hits += global_equal(rest, a.blob + w, m - w);
-                        }
-                    }
-                }
-            };
-            if (jb >= j0 && jb + 64u <= jend) {
-                // the whole half is inside the run (all but a run's first/last): straight-
-                // line code, the gathers of a batch are in flight under the recurrence
-                constexpr int CB = LONG ? 2 : 4;  // 16-byte chunks per gather batch (the long-
-                                                  // pattern instantiation needs the registers)
-#pragma unroll
-                for (int nb = 0; nb < 4 / CB; ++nb) {
-                    uint32_t sv[16 * CB];
-#pragma unroll
-                    for (int c4 = 0; c4 < CB; ++c4) {
-                        const uint4 v = run_piece(io, CB * nb + c4);
-                        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int q = 0; q < 16; ++q)
-                            sv[16 * c4 + q] = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
-                    }
-#pragma unroll
-                    for (int h = 0; h < CB / 2; ++h) {
-                        uint32_t H = hinit;
-#pragma unroll
-                        for (int q = 0; q < 32; ++q) {
-                            if (AND) D = ((D << 1) | one) & sv[32 * h + q];  // sa.c:52
-                            else D = (D << 1) | sv[32 * h + q];              // so.c:55
-                            H = __builtin_amdgcn_alignbit(H, D, 31);  // so.c:56 / sa.c:53: the sign bit is the hit test
-                        }
-                        const uint32_t hm = AND ? H : ~H;
-                        const uint32_t base = jb + 16u * CB * nb + 32u * h;
-                        if (!LONG) {
-                            hits += __popc(hm);
-                        } else {
-                            take_hits(base, hm >> 16);
-                            take_hits(base + 16u, hm & 0xFFFFu);
-                        }
-                    }
-                }
-            } else {
-#pragma unroll 1
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    const uint32_t base = jb + 16u * c4;
-                    if (base >= jend || base + 16 <= j0) continue;
-                    const uint4 v = run_piece(io, c4);
-                    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-                    uint32_t H = hinit;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const uint32_t j = base + q;
-                        uint32_t sv = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
-                        sv = (j >= j0 && j < jend) ? sv : sentinel;
-                        if (AND) D = ((D << 1) | one) & sv;
-                        else D = (D << 1) | sv;
-                        H = __builtin_amdgcn_alignbit(H, D, 31);
-                    }
-                    take_hits(base, (AND ? H : ~H) & 0xFFFFu);
-                }
-            }
-            if (LONG && __any(parked)) {  // keep at most one parked window per lane
-                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
-                parked = false;
-            }
-        };
-        for (uint32_t k = 0; k < nlines; ++k) {
-            LINE_PARK(io, true);
-            half(k * kRunLine);
-            LINE_PARK(io, false);
-            if (k + 1 < nlines) LINE_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
-            half(k * kRunLine + 64u);
-        }
-    }
-    flush_hits(hits, a.count, smem);
-}
-
 // ---- the whole-line loader with half-swapped registers (so_runs, kmp_runs) ----------------------
 // LineIo's loads (every 128-byte line requested by ONE non-temporal instruction) with RunIo's parking
 // cost.  Load i fetches the lines of runs 8i .. 8i+7 with lane = 32*half + 4*(run in block) + piece:
@@ -1851,12 +1100,6 @@ __device__ __forceinline__ uint32_t lshl_or_now(uint32_t a, uint32_t b)
     return r;
 }
 
-#ifndef SG_EARLY
-#define SG_EARLY 0  // experiments: 1 = half of the next line's loads already after the first park (kmp_runs: 4 % slower, so_runs: equal)
-#endif
-#ifndef SG_ABLATE
-#define SG_ABLATE 0  // experiments only (wrong counts): 1 no gathers, 2 no recurrence, 4 no parking, 8 no fetch after line 0
-#endif
 template <bool LONG>  // LONG: m > 29, hits of the 29-byte prefix are verified
 __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns, const ScanArgs* __restrict__ batch)
 {
@@ -1873,7 +1116,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
     uint4 n0, n1, n2, n3, n4, n5, n6, n7;
     bool fetched = false;
     {
-        const uint64_t g = blockIdx.x + (uint64_t)gridDim.x * (threadIdx.x >> 6);
+        const uint64_t g = first_group(nruns, 64, kRunWaves, threadIdx.x >> 6);
         if (g * 64 < nruns) {
             const RunIo io0 = swap_io(smem, threadIdx.x & 63u, run_len);  // only loff is used
             const uint8_t* const gbase = a.text + (a.s_begin / run_len + g * 64) * run_len + io0.loff;
@@ -1904,7 +1147,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
     const uint64_t run_first = a.s_begin / run_len;
     const uint64_t nwaves = (uint64_t)gridDim.x * kRunWaves;
     const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
-    for (uint64_t g = blockIdx.x + (uint64_t)gridDim.x * wave; g * 64 < nruns; g += nwaves) {
+    for (uint64_t g = first_group(nruns, 64, kRunWaves, wave); g * 64 < nruns; g += nwaves) {
         const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
         uint32_t blk[8];  // a block that lies entirely past the last run re-reads block 0 (loaded, never consumed)
 #pragma unroll
@@ -1953,10 +1196,8 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
                 auto gather16 = [&](const uint4& vv, uint32_t* out) {
                     const uint32_t d[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        if (SG_ABLATE & 1) out[q] = __builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
-                        else out[q] = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
-                    }
+                    for (int q = 0; q < 16; ++q)
+                        out[q] = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
                 };
                 gather16(v[0], s[0]);
                 uint32_t H[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -1965,12 +1206,6 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
                     if (c4 < 3) gather16(v[c4 + 1], s[(c4 + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     const uint32_t* sc = s[c4 & 1];
-                    if (SG_ABLATE & 2) {
-#pragma unroll
-                        for (int k = 0; k < 16; k += 4) D |= sc[k] | sc[k + 1] | sc[k + 2] | sc[k + 3];
-                        __builtin_amdgcn_sched_barrier(0);
-                        continue;
-                    }
                     uint32_t pr[8], t[4];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) pr[k] = lshl_or_now<1>(sc[2 * k], sc[2 * k + 1]);
@@ -2019,12 +1254,10 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
         };
         for (uint32_t k = 0; k < nlines; ++k) {
             SWAP_LINE();
-            if (!(SG_ABLATE & 4) || k == 0) RUN_PARK(io, n0, n2, n4, n6);
-            if (SG_EARLY && k + 1 < nlines && !(SG_ABLATE & 8)) LINE_FETCH_EVEN(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
+            RUN_PARK(io, n0, n2, n4, n6);
             half(k * kRunLine);
-            if (!(SG_ABLATE & 4) || k == 0) RUN_PARK(io, n1, n3, n5, n7);
-            if (SG_EARLY && k + 1 < nlines && !(SG_ABLATE & 8)) LINE_FETCH_ODD(gbase, blk, (k + 1) * kRunLine);
-            if (!SG_EARLY && k + 1 < nlines && !(SG_ABLATE & 8)) LINE_FETCH(gbase, blk, (k + 1) * kRunLine);
+            RUN_PARK(io, n1, n3, n5, n7);
+            if (k + 1 < nlines) LINE_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
             half(k * kRunLine + 64u);
         }
     }
@@ -2110,7 +1343,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     uint4 n0, n1, n2, n3, n4, n5, n6, n7;
     bool fetched = false;
     {
-        const uint64_t g = blockIdx.x + (uint64_t)gridDim.x * (threadIdx.x >> 6);
+        const uint64_t g = first_group(nruns, 64, kRunWaves, threadIdx.x >> 6);
         if (g * 64 < nruns) {
             const RunIo io0 = RUNIO ? run_io(smem, threadIdx.x & 63u, run_len) : swap_io(smem, threadIdx.x & 63u, run_len);  // only loff is used
             const uint8_t* const gbase = a.text + (a.s_begin / run_len + g * 64) * run_len + io0.loff;
@@ -2138,7 +1371,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     const uint64_t run_first = a.s_begin / run_len;  // runs are cut on absolute offsets
     const uint64_t nwaves = (uint64_t)gridDim.x * kRunWaves;
     const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
-    for (uint64_t g = blockIdx.x + (uint64_t)gridDim.x * wave; g * 64 < nruns; g += nwaves) {
+    for (uint64_t g = first_group(nruns, 64, kRunWaves, wave); g * 64 < nruns; g += nwaves) {
         const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
         uint32_t blk[8];  // a block that lies entirely past the last run re-reads block 0 (loaded, never consumed)
 #pragma unroll
@@ -2245,113 +1478,11 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     flush_hits(hits, a.count, smem);
 }
 
-// The first runs kernel: shared 1 KB table, 64-byte steps, [run][80 B] slabs (A/B only).
-template <bool LONG>
-__global__ __launch_bounds__(256) void so_runs64(ScanArgs a1, uint32_t run_len, uint64_t nruns, const ScanArgs* __restrict__ batch)
-{
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t m = a.m, w = m < 32 ? m : 32;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* S = reinterpret_cast<uint32_t*>(smem);  // 257 entries, padded to 1040 B
-    uint8_t* slab = smem + 1040 + wave * kRunSlab;
-    for (uint32_t i = threadIdx.x; i < 257; i += 256)
-        S[i] = (i < 256 ? reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] : 0xFFFFFFFFu) << (32 - w);
-    __syncthreads();  // the only workgroup barrier: table visible
-
-    uint32_t hits = 0;
-    const uint64_t run_first = a.s_begin / run_len;
-    const uint64_t nwaves = (uint64_t)gridDim.x * 4;
-    const uint32_t nsteps = (run_len + w - 1 + 63) / 64;
-    for (uint64_t g = (uint64_t)blockIdx.x * 4 + wave; g * 64 < nruns; g += nwaves) {
-        const uint8_t* src[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint64_t r = g * 64 + 16 * i + (lane >> 2);
-            if (r >= nruns) r = nruns - 1;  // clamp: loaded but never consumed
-            src[i] = a.text + (run_first + r) * run_len + (lane & 3u) * 16u;
-        }
-        const uint64_t my = g * 64 + lane;
-        const uint64_t seg = (run_first + my) * run_len;
-        const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
-        const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
-        const bool owner = my < nruns && sa < sb;
-        const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
-        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
-
-        uint4 nx0 = *reinterpret_cast<const uint4*>(src[0]);
-        uint4 nx1 = *reinterpret_cast<const uint4*>(src[1]);
-        uint4 nx2 = *reinterpret_cast<const uint4*>(src[2]);
-        uint4 nx3 = *reinterpret_cast<const uint4*>(src[3]);
-        uint32_t D = 0xFFFFFFFFu << (32 - w);
-        bool parked = false;
-        const uint8_t* parked_at = a.text;
-        for (uint32_t k = 0; k < nsteps; ++k) {
-            {
-                uint8_t* dst = slab + (lane >> 2) * 80u + (lane & 3u) * 16u;
-                *reinterpret_cast<uint4*>(dst) = nx0;
-                *reinterpret_cast<uint4*>(dst + 16 * 80) = nx1;
-                *reinterpret_cast<uint4*>(dst + 32 * 80) = nx2;
-                *reinterpret_cast<uint4*>(dst + 48 * 80) = nx3;
-            }
-            if (k + 1 < nsteps) {
-                const uint32_t o = (k + 1) * 64u;
-                nx0 = *reinterpret_cast<const uint4*>(src[0] + o);
-                nx1 = *reinterpret_cast<const uint4*>(src[1] + o);
-                nx2 = *reinterpret_cast<const uint4*>(src[2] + o);
-                nx3 = *reinterpret_cast<const uint4*>(src[3] + o);
-            }
-            const uint8_t* mine = slab + lane * 80u;
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const uint32_t base = k * 64u + 16u * c4;
-                if (base >= jend || base + 16 <= j0) continue;
-                const uint4 v = *reinterpret_cast<const uint4*>(mine + 16 * c4);
-                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-                const bool full = base >= j0 && base + 16 <= jend;
-                uint32_t sv[16];
-                if (full) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) sv[q] = S[(d[q >> 2] >> (8 * (q & 3))) & 0xFFu];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const uint32_t j = base + q;
-                        const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
-                        sv[q] = S[(j >= j0 && j < jend) ? c : 256u];
-                    }
-                }
-                uint32_t H = 0xFFFFFFFFu;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    D = (D << 1) | sv[q];                     // so.c:55
-                    H = __builtin_amdgcn_alignbit(H, D, 31);  // so.c:56: sign bit clear <=> hit
-                }
-                uint32_t hm = ~H & 0xFFFFu;
-                if (!LONG) {
-                    hits += __popc(hm);
-                } else {
-                    while (hm) {  // 32-byte prefix matched, ending at byte q: verify P[32..m)
-                        const uint32_t bit = 31u - __builtin_clz(hm);
-                        hm &= ~(1u << bit);
-                        const uint8_t* rest = a.text + seg + base + (15u - bit) + 1;
-                        if (!parked) {
-                            parked = true;
-                            parked_at = rest;
-                        } else {
-                            hits += global_equal(rest, a.blob + w, m - w);
-                        }
-                    }
-                }
-            }
-            if (LONG && __any(parked)) {  // keep at most one parked window per lane
-                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
-                parked = false;
-            }
-        }
-    }
-    flush_hits(hits, a.count, smem);
-}
+#ifdef SMARTGPU_AB
+// The superseded kernels kept for A/B measurements (so_scan, so_runs64, so_runs1, kmp_scan, kmp_links_runs,
+// kmp_runs1 and their loaders): only in the A/B build (make AB=1 -> libsmartgpu_ab.so), selected by smartgpu_tune.
+#include "kernels_ab.inc"
+#endif
 
 // ---------------------------------------------------------------------------
 // EPSM — packed matching  (reference: src/algos/epsm.c; its SSE regimes —
@@ -2734,6 +1865,21 @@ hipError_t launch_tiled(K kernel, const ScanArgs& a, TileRange tr, int threads, 
 
 int g_tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
+// Which smartgpu_tune settings this build can honour: the kernels behind the others are only in the A/B build.
+bool tune_supported(int key, int value)
+{
+#ifdef SMARTGPU_AB
+    (void)key; (void)value;
+    return true;
+#else
+    switch (key) {
+        case 0: return value == 0 || value == 1 || value == 3;  // 2: Horspool on the bank-private tiles
+        case 3: case 6: case 7: return value == 0;               // superseded KMP / SO kernels, packed load policies
+        default: return true;
+    }
+#endif
+}
+
 // skip algorithms use the packed matcher up to this m (crossovers measured on 1 GiB rand128
 // with non-temporal tile loads, profiles/r01): HOR/TUNEDBM/RAITA 7, BM 8, BNDM 11, QS 14, HASH3/5/8 32/64/28
 static constexpr uint32_t packed_max_m(int algo)
@@ -2751,14 +1897,27 @@ static constexpr uint32_t packed_max_m(int algo)
 constexpr int kHorT = 256, kHorL = 64;
 constexpr int kBmT = 256, kBmL = 64;
 constexpr int kBndmT = 256, kBndmL = 64;
-constexpr int kSoT = 256, kSoL = 80;
+#ifdef SMARTGPU_AB
+constexpr int kSoT = 256, kSoL = 80;  // so_scan
+#endif
 constexpr int kEpsmT = 256;
 
 static int hor_regime(uint32_t m, int algo = SMARTGPU_HOR);
 
 const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_masks)
 {
-    if (so_masks && g_tune[0] == 0) return g_tune[6] == 4 ? "so_runs1" : "so_runs";
+#ifdef SMARTGPU_AB
+    const char* const so_name = g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : g_tune[6] == 4 ? "so_runs1" : "so_runs";
+    const char* const sa_name = (g_tune[6] == 3 || g_tune[6] == 4) ? "so_runs1" : "so_runs";
+    const char* const kmp_name = (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : g_tune[3] == 3 ? "kmp_runs1" : "kmp_runs";
+    const char* const reroute_name = g_tune[6] == 4 ? "so_runs1" : "so_runs";
+#else
+    const char* const so_name = "so_runs";
+    const char* const sa_name = "so_runs";
+    const char* const kmp_name = "kmp_runs";
+    const char* const reroute_name = "so_runs";
+#endif
+    if (so_masks && g_tune[0] == 0) return reroute_name;
     const bool pk = prefer_packed && g_tune[0] == 0;
     switch (algo) {
         case SMARTGPU_TUNEDBM:
@@ -2771,11 +1930,11 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_m
         case SMARTGPU_HASH8:
         case SMARTGPU_RAITA:
         case SMARTGPU_QS: return (pk || hor_regime(m, algo) == 3) ? "packed_scan" : "hor_scan";
-        case SMARTGPU_SA: return (g_tune[6] == 3 || g_tune[6] == 4) ? "so_runs1" : "so_runs";
+        case SMARTGPU_SA: return sa_name;
         case SMARTGPU_KR: return (m < 16 && g_tune[0] != 1) ? "packed_scan" : "hor_scan_bp";
-        case SMARTGPU_BM: return (pk || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
-        case SMARTGPU_KMP: return (g_tune[3] == 1 && m <= 40) ? "kmp_scan" : g_tune[3] == 2 ? "kmp_links_runs" : g_tune[3] == 3 ? "kmp_runs1" : "kmp_runs";
-        case SMARTGPU_SO: return g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : g_tune[6] == 4 ? "so_runs1" : "so_runs";
+        case SMARTGPU_BM: return (pk || m == 1 || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1)) ? "packed_scan" : "bm_scan";
+        case SMARTGPU_KMP: return kmp_name;
+        case SMARTGPU_SO: return so_name;
         case SMARTGPU_BNDML:
             if (m > 32) return pk ? "packed_scan" : "bndml_scan";
             [[fallthrough]];
@@ -2833,32 +1992,43 @@ static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus,
     const size_t lds = 65536 + kRunWaves * (size_t)kLineSlab;
     uint64_t grid = ((uint64_t)tr.count + 63) / 64;  // groups of 64 runs: spread over the CUs first (so_runs: group = block + grid * wave)
     if (grid > (uint64_t)num_cus) grid = num_cus;
+#ifdef SMARTGPU_AB
 #define SG_SO_RUNS1(L_, A_)                                                                               \
     do {                                                                                                 \
         allow_lds(reinterpret_cast<const void*>(so_runs1<L_, A_>), lds);                                  \
         hipLaunchKernelGGL((so_runs1<L_, A_>), dim3((uint32_t)grid, g_batch.count), dim3(64 * kRunWaves), lds, stream, a, \
                            (uint32_t)L, (uint64_t)tr.count, g_batch.items);                              \
     } while (0)
+#endif
 #define SG_SO_RUNS(L_)                                                                                   \
     do {                                                                                                 \
         allow_lds(reinterpret_cast<const void*>(so_runs<L_>), lds);                                      \
         hipLaunchKernelGGL((so_runs<L_>), dim3((uint32_t)grid, g_batch.count), dim3(64 * kRunWaves), lds, stream, a, \
                            (uint32_t)L, (uint64_t)tr.count, g_batch.items);                              \
     } while (0)
+#ifdef SMARTGPU_AB
     if (shift_and) { if (m > 32) SG_SO_RUNS1(true, true); else SG_SO_RUNS1(false, true); }
     else if (g_tune[6] == 4) { if (m > 32) SG_SO_RUNS1(true, false); else SG_SO_RUNS1(false, false); }
-    else { if (m > kSoWindow) SG_SO_RUNS(true); else SG_SO_RUNS(false); }
-#undef SG_SO_RUNS
+    else
 #undef SG_SO_RUNS1
+#endif
+    { if (m > kSoWindow) SG_SO_RUNS(true); else SG_SO_RUNS(false); }
+    (void)shift_and;
+#undef SG_SO_RUNS
     return hipGetLastError();
 }
 
 static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream)
 {
     const uint32_t m = a.m;
-    const bool links = g_tune[3] == 2;                       // failure links, A/B
-    uint32_t w = (links || m <= kKmpDfaMaxM) ? m : kKmpDfaMaxM;  // bytes re-scanned per run: w-1
-    const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));
+    const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));  // the transition table of kmp_runs (api.cpp build_blob)
+    uint32_t w = m < kKmpWindow ? m : kKmpWindow;           // bytes the automaton recognises; a run re-scans w-1
+    const uint32_t rows = w < 63 ? 4 * w + 2 : 256;         // up to the absorbing row Z
+#ifdef SMARTGPU_AB
+    const bool links = g_tune[3] == 2;  // failure links
+    const bool v1 = g_tune[3] == 3;     // the previous kernel (running maximum, half-line loader): its table follows
+    const uint32_t dfa1_off = dfa_off + rows * 256;
+    if (links || v1) w = (links || m <= kKmpDfaMaxM) ? m : kKmpDfaMaxM;
     if (links) {
         const uint64_t span = a.s_end - a.s_begin;
         uint64_t L = 8ull * (w - 1);
@@ -2874,15 +2044,15 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
         const uint64_t cap = (uint64_t)num_cus * 4;
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL(kmp_links_runs, dim3((uint32_t)grid, g_batch.count), dim3(256), lds, stream, a, (uint32_t)L,
-                           (uint64_t)tr.count, dfa_off, g_batch.items);
+                           (uint64_t)tr.count, dfa1_off, g_batch.items);
         return hipGetLastError();
     }
+    const size_t table = v1 ? (size_t)(w < 64 ? 4 * w + 1 : 256) * 256 : (size_t)rows * 256;  // kmp_runs1: rows up to the accept id
+#else
+    const size_t table = (size_t)rows * 256;
+#endif
     // one 1024-thread workgroup per CU shares the table (<= 64 KB) next to 16 x 4 KB of slabs
-    const bool v1 = g_tune[3] == 3;  // the previous kernel (running maximum, half-line loader), A/B
-    const uint32_t w2 = m < kKmpWindow ? m : kKmpWindow;
-    if (!v1) w = w2;
-    const size_t lds = (v1 ? (size_t)(w < 64 ? 4 * w + 1 : 256) : (size_t)(w2 < 63 ? 4 * w2 + 2 : 256)) * 256
-                       + kRunWaves * (size_t)kLineSlab;  // rows up to the accept id (kmp_runs1) / up to Z (kmp_runs)
+    const size_t lds = table + kRunWaves * (size_t)kLineSlab;
     // runs of 2-4 KiB: at least 8x the w-1 bytes a run re-scans, at most 8 KiB (the loader's
     // over-read past the last run stays inside the text's back pad)
     uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
@@ -2899,13 +2069,16 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
         hipLaunchKernelGGL(K_, dim3((uint32_t)grid, g_batch.count), dim3(64 * kRunWaves), lds, stream, a, (uint32_t)L, \
                            (uint64_t)tr.count, (uint32_t)(OFF_), g_batch.items);                         \
     } while (0)
+#ifdef SMARTGPU_AB
     if (v1) {
-        if (m > kKmpDfaMaxM) SG_KMP_RUNS(kmp_runs1<true>, dfa_off); else SG_KMP_RUNS(kmp_runs1<false>, dfa_off);
-    } else {
+        if (m > kKmpDfaMaxM) SG_KMP_RUNS(kmp_runs1<true>, dfa1_off); else SG_KMP_RUNS(kmp_runs1<false>, dfa1_off);
+    } else
+#endif
+    {
         // 63+ states: the full 64 KB table, behind the half-line loader (see kmp_runs)
-        if (m > kKmpWindow) SG_KMP_RUNS((kmp_runs<true, true>), dfa_off + 65536);
-        else if (w2 >= 63) SG_KMP_RUNS((kmp_runs<false, true>), dfa_off + 65536);
-        else SG_KMP_RUNS((kmp_runs<false, false>), dfa_off + 65536);
+        if (m > kKmpWindow) SG_KMP_RUNS((kmp_runs<true, true>), dfa_off);
+        else if (w >= 63) SG_KMP_RUNS((kmp_runs<false, true>), dfa_off);
+        else SG_KMP_RUNS((kmp_runs<false, false>), dfa_off);
     }
 #undef SG_KMP_RUNS
     return hipGetLastError();
@@ -2929,12 +2102,16 @@ static hipError_t launch_packed(const ScanArgs& a, int num_cus, hipStream_t stre
 #define SG_PACKED(M_, P_)                                                                           \
     hipLaunchKernelGGL((packed_scan<kEpsmT, 4, ALGO, M_, P_>), dim3((uint32_t)grid, g_batch.count), dim3(kEpsmT), 128, \
                        stream, a, tr.first, (uint64_t)tr.count, g_batch.items)
+#ifdef SMARTGPU_AB  // the other load policies: both loads cached (1), one non-temporal load + shuffle (3)
 #define SG_PACKED_POLICY(M_)                                                 \
     do {                                                                     \
         if (g_tune[7] == 1) SG_PACKED(M_, 1);                                \
         else if (g_tune[7] == 3) SG_PACKED(M_, 3);                           \
         else SG_PACKED(M_, 0);                                               \
     } while (0)
+#else
+#define SG_PACKED_POLICY(M_) SG_PACKED(M_, 0)
+#endif
     if (a.m > 16) SG_PACKED_POLICY(2);
     else if (a.m % 4 == 0) SG_PACKED_POLICY(1);
     else SG_PACKED_POLICY(0);
@@ -3023,11 +2200,13 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
             if (regime == 3) {
                 return launch_packed<SMARTGPU_HOR>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
             }
-            if (regime == 2) {
+#ifdef SMARTGPU_AB
+            if (regime == 2) {  // Horspool on the bank-private tiles (tune(0,2)); the product uses that kernel for Karp-Rabin only
                 const size_t lds = kBpTabBytes + r16(H + 1) + kBpTextBytes;
                 const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBpThreads * kBpL);
                 return launch_tiled(hor_scan_bp<false>, a, tr, kBpThreads, lds, 5, num_cus, stream);
             }
+#endif
             const size_t lds = 512 + r16(H + 1) + ((r16(H) + (size_t)kHorT * kHorL + 16 + 63) & ~(size_t)63);  // whole 64-byte blocks: tile_at() permutes inside them
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
             if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 0>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);
@@ -3070,7 +2249,9 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
             return launch_tiled(hor_scan<kHorT, kHorL, false, 1>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);
         }
         case SMARTGPU_BM: {
-            if ((m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
+            // m = 1 always: bm_scan reads the byte before the window's last along with it, and a one-byte
+            // window has none (at a tile's first byte that read would leave the tile region)
+            if (m == 1 || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1) || (a.prefer_packed && g_tune[0] == 0)) {
                 return launch_packed<SMARTGPU_BM>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
             }
             const uint32_t H = a.halo;
@@ -3115,7 +2296,8 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
         }
         case SMARTGPU_SA:  // Shift-And: so_runs1<.., AND = true>; the A/B kernels below are Shift-Or only
         case SMARTGPU_SO: {
-            if (g_tune[6] == 2 && algo == SMARTGPU_SO) {  // the first runs kernel: shared table, 64-byte steps (A/B)
+#ifdef SMARTGPU_AB
+            if (g_tune[6] == 2 && algo == SMARTGPU_SO) {  // the first runs kernel: shared table, 64-byte steps
                 uint64_t L = g_tune[5] ? (uint64_t)g_tune[5] : 1024;
                 const uint64_t fill = (a.s_end - a.s_begin) / ((uint64_t)num_cus * 16 * 64);
                 if (L > fill) L = fill;
@@ -3133,35 +2315,35 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
                     hipLaunchKernelGGL(so_runs64<false>, dim3((uint32_t)grid, g_batch.count), dim3(256), lds, stream, a, (uint32_t)L, (uint64_t)tr.count, g_batch.items);
                 return hipGetLastError();
             }
-            if (g_tune[6] != 1 || algo == SMARTGPU_SA) {  // per-lane runs through LDS line slabs (tune[6]=1: LDS tiles, for A/B)
-                // a.so_off: prepare_scan_args (Shift-And counts in the complemented, Shift-Or form by default:
-                // api.cpp build_blob; its own AND form — so_runs1<.., AND = true>, masks after the Shift-Or ones — with tune(6,3))
-                const bool and_form = algo == SMARTGPU_SA && g_tune[6] == 3;
-                return launch_so_runs(a, and_form, num_cus, stream);
+            if (g_tune[6] == 1 && algo == SMARTGPU_SO) {  // LDS tiles
+                const size_t lds = 1040 + (size_t)kSoT * kSoL + 32;
+                const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kSoT * kSoL);
+                if (m > 32) return launch_tiled(so_scan<kSoT, kSoL, true>, a, tr, kSoT, lds, 6, num_cus, stream);
+                return launch_tiled(so_scan<kSoT, kSoL, false>, a, tr, kSoT, lds, 6, num_cus, stream);
             }
-            const size_t lds = 1040 + (size_t)kSoT * kSoL + 32;
-            const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)kSoT * kSoL);
-            if (m > 32) return launch_tiled(so_scan<kSoT, kSoL, true>, a, tr, kSoT, lds, 6, num_cus, stream);
-            return launch_tiled(so_scan<kSoT, kSoL, false>, a, tr, kSoT, lds, 6, num_cus, stream);
+#endif
+            // a.so_off: prepare_scan_args.  Shift-And counts in the complemented, Shift-Or form (api.cpp build_blob); its
+            // own AND form (so_runs1<.., AND = true>, masks after the Shift-Or ones) is in the A/B build: tune(6,3)
+            return launch_so_runs(a, algo == SMARTGPU_SA && g_tune[6] == 3, num_cus, stream);
         }
         case SMARTGPU_KMP: {
-            // m <= 40: LDS tiles, run length per lane 80 or 144 bytes (re-scan of m-1 bytes <~28 %)
+#ifdef SMARTGPU_AB
+            // tune(3,1), m <= 40: LDS tiles, run length per lane 80 or 144 bytes (re-scan of m-1 bytes <~28 %), failure links
             const size_t fixed = r16(4 * m) + r16(m - 1);
 #define SG_KMP(T_, L_, WGS_)                                                                   \
     do {                                                                                       \
         const size_t lds = fixed + (size_t)(T_) * (L_);                                        \
-        if (lds > 64 * 1024)                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kmp_scan<T_, L_>),         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        if (lds > 64 * 1024) allow_lds(reinterpret_cast<const void*>(kmp_scan<T_, L_>), lds);  \
         const TileRange tr = tiles_for(a.s_begin, a.s_end, (uint64_t)(T_) * (L_));            \
         return launch_tiled(kmp_scan<T_, L_>, a, tr, T_, lds, WGS_, num_cus, stream);          \
     } while (0)
-            if (g_tune[3] == 1) {  // LDS-tile kernel (failure links), for A/B
+            if (g_tune[3] == 1) {
                 if (m <= 16) SG_KMP(256, 80, 6);
                 if (m <= 40) SG_KMP(256, 144, 4);
             }
 #undef SG_KMP
-            // per-lane runs streamed through LDS (kmp_runs1)
+#endif
+            // per-lane runs streamed through LDS
             return launch_kmp_runs(a, num_cus, stream);
         }
         case SMARTGPU_EPSM: {

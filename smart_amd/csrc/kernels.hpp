@@ -72,6 +72,7 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_m
 
 // tuning knobs (smartgpu_tune): [0] HOR variant 0 auto / 1 flat / 2 bank-private
 extern int g_tune[8];
+bool tune_supported(int key, int value);  // false: the setting needs the A/B build (make AB=1)
 
 // text generators / helpers (device side)
 hipError_t launch_generate(uint8_t* dst, uint64_t seed, int sigma, uint64_t off, uint64_t n,

@@ -15,6 +15,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SMARTGPU_LIB overrides the library path (A/B runs of two builds in one session)
 LIB_PATH = os.environ.get("SMARTGPU_LIB") or os.path.join(_HERE, "csrc", "libsmartgpu.so")
+# the product library plus the superseded kernels (smartgpu_tune selects them): A/B tests and measurements
+AB_LIB_PATH = os.path.join(_HERE, "csrc", "libsmartgpu_ab.so")
 ALGOS = ("hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8", "sbndm", "kr", "bndml")
 # shortest pattern each algorithm applies to (the reference returns -1 below: raita.c:37, hash3.c:31, ...)
 MIN_M = {"raita": 2, "hash3": 3, "hash5": 5, "hash8": 8, "sbndm": 2}
@@ -31,13 +33,30 @@ def build():
     subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
 
 
+_loaded = {}
+
+
+def use_library(path=None):
+    """Make `path` (default: the product library) the library new Text / Plan objects and the module-level
+    calls go to.  Objects made earlier keep the library that made them (they free through it)."""
+    global _lib
+    _lib = _load(path or LIB_PATH)
+    return _lib
+
+
 def lib():
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise SmartGpuError("%s is missing: run `make -C smart_amd/csrc` (or __graft_entry__.build())" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    if _lib is None:
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+def _load(path):
+    if path in _loaded:
+        return _loaded[path]
+    if not os.path.exists(path):
+        raise SmartGpuError("%s is missing: run `make -C smart_amd/csrc` (or __graft_entry__.build())" % path)
+    L = C.CDLL(path)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     sig = {
         "smartgpu_version": (C.c_char_p, []),
@@ -86,7 +105,7 @@ def lib():
         f = getattr(L, name)
         f.restype = res
         f.argtypes = args
-    _lib = L
+    _loaded[path] = L
     return L
 
 
@@ -125,6 +144,7 @@ class Text:
         if not handle:
             raise _err("text")
         self._h = handle
+        self._L = lib()  # the library that made the handle frees it
 
     @classmethod
     def upload(cls, data, device=0):
@@ -159,7 +179,7 @@ class Text:
 
     def free(self):
         if self._h:
-            lib().smartgpu_text_free(self._h)
+            self._L.smartgpu_text_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -175,7 +195,8 @@ class Plan:
     def __init__(self, algo, P, device=0):
         self.P = _u8(P)
         self.algo = algo
-        self._h = lib().smartgpu_plan_create(algo_id(algo), self.P.ctypes.data, len(self.P), device)
+        self._L = lib()
+        self._h = self._L.smartgpu_plan_create(algo_id(algo), self.P.ctypes.data, len(self.P), device)
         if not self._h:
             raise _err("plan_create")
 
@@ -210,7 +231,7 @@ class Plan:
 
     def free(self):
         if self._h:
-            lib().smartgpu_plan_free(self._h)
+            self._L.smartgpu_plan_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -227,6 +248,7 @@ class MultiText:
         if not handle:
             raise _err("mtext")
         self._h = handle
+        self._L = lib()
 
     @staticmethod
     def _devs(devices):
@@ -275,7 +297,7 @@ class MultiText:
 
     def free(self):
         if self._h:
-            lib().smartgpu_mtext_free(self._h)
+            self._L.smartgpu_mtext_free(self._h)
             self._h = None
 
     def __del__(self):

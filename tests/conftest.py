@@ -38,3 +38,17 @@ def fuzz_case(po, row):
     if row["kind"] == "mutated":
         P[row["mut"]] = (int(P[row["mut"]]) + 1) % row["sigma"]
     return P, T
+
+
+@pytest.fixture
+def ab_library():
+    """The A/B build of the library (the product plus the superseded kernels of kernels_ab.inc, which
+    smartgpu_tune selects) for the duration of one test; everything the test creates goes through it."""
+    from smart_amd import engine
+    L = engine.use_library(engine.AB_LIB_PATH)
+    try:
+        yield L
+    finally:
+        for key in range(8):
+            L.smartgpu_tune(key, 0)
+        engine.use_library()

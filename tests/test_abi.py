@@ -203,3 +203,34 @@ def test_kernel_choice_follows_the_pattern(oracle):
         engine.tune(0, 0)
     with pytest.raises(smart_amd.SmartGpuError):
         kf("hash8", rnd[:7])
+
+
+def test_product_library_carries_no_superseded_kernels():
+    """The product library exports every declared symbol and refuses the smartgpu_tune settings whose kernels
+    live only in the A/B build (kernels_ab.inc); the A/B build exports the same ABI and accepts them."""
+    from smart_amd import engine
+    for key, value in ((3, 1), (3, 2), (3, 3), (6, 1), (6, 2), (6, 3), (6, 4), (7, 1), (7, 3), (0, 2)):
+        with pytest.raises(smart_amd.SmartGpuError) as e:
+            engine.tune(key, value)
+        assert "A/B build" in str(e.value)
+    for key, value in ((0, 1), (0, 3), (0, 0), (4, 6), (4, 0), (5, 1024), (5, 0)):
+        engine.tune(key, value)
+    prod = open(engine.LIB_PATH, "rb").read()
+    for name in (b"so_runs64", b"kmp_links_runs", b"so_scan", b"kmp_scan", b"kmp_runs1", b"so_runs1"):
+        assert name not in prod, name
+    ab = ctypes.CDLL(engine.AB_LIB_PATH)
+    for n in declared_symbols():
+        assert hasattr(ab, n), n
+    assert os.path.getsize(engine.LIB_PATH) < 0.7 * os.path.getsize(engine.AB_LIB_PATH)
+    L = engine.use_library(engine.AB_LIB_PATH)
+    try:
+        assert b"A/B" in L.smartgpu_version()
+        engine.tune(3, 3)
+        assert smart_amd.kernel_for("kmp", b"abcdabcd") == "kmp_runs1"
+        engine.tune(3, 0)
+        engine.tune(6, 2)
+        assert smart_amd.kernel_for("so", b"abcdabcd") == "so_runs64"
+        engine.tune(6, 0)
+    finally:
+        engine.use_library()
+    assert smart_amd.kernel_for("kmp", b"abcdabcd") == "kmp_runs"

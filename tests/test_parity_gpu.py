@@ -60,7 +60,7 @@ def test_fuzz_vectors(oracle):
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3])
-def test_horspool_variants(oracle, variant):
+def test_horspool_variants(oracle, ab_library, variant):
     """All Horspool regimes (flat LDS tile / bank-private layout / packed) on the fuzz
     vectors, the dense small-alphabet case and sub-ranges."""
     from smart_amd import engine
@@ -102,7 +102,7 @@ def test_skip_loops_forced_for_short_patterns(oracle):
 
 
 @pytest.mark.parametrize("policy", [1, 3])
-def test_packed_load_policies(oracle, policy):
+def test_packed_load_policies(oracle, ab_library, policy):
     """The packed matcher's alternative data paths (both loads cached / one
     non-temporal load + cross-lane shuffle) give the same counts."""
     from smart_amd import engine
@@ -126,7 +126,7 @@ def test_packed_load_policies(oracle, policy):
 
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 4])
-def test_alternate_serial_kernels(oracle, variant):
+def test_alternate_serial_kernels(oracle, ab_library, variant):
     """SO and KMP normally run on the bank-private / full-table runs kernels; the variants kept
     for A/B measurements must give the same counts: 1 = LDS tiles (so_scan, kmp_scan),
     2 = shared-table so_runs and the failure-link kmp_links_runs, 3 = Shift-And in its own AND

@@ -33,19 +33,19 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--tune", default="", help="comma list key=value passed to smartgpu_tune")
     ap.add_argument("--corpus", default="rand", help="rand (counter-based rand<sigma>) or english "
-                    "(tests/golden/english_excerpt.txt replicated to --gib, BASELINE config 4 style)")
+                    "(bible.txt||world192.txt, 6,520,792 bytes, tiled to --gib: BASELINE config 4)")
+    ap.add_argument("--own", action="store_true", help="smartgpu_tune(0,1): every algorithm on its own kernel, no rerouting")
     args = ap.parse_args()
     for kv in filter(None, args.tune.split(",")):
         k, v = kv.split("=")
         smart_amd.engine.tune(int(k), int(v))
+    if args.own:
+        smart_amd.engine.tune(0, 1)
     n = int(args.gib * (1 << 30))
+    unit = None
     if args.corpus == "english":
-        unit = np.fromfile(os.path.join(ROOT, "tests", "golden", "english_excerpt.txt"), dtype=np.uint8)
-        # 262,139 bytes (a prime), not the file's 2^18: with a power-of-two period every occurrence of a
-        # pattern falls on the same few tile residues and so on the same few workgroups of a grid-strided
-        # kernel (64 of 1024), which then serialise all the verification work — an artefact of the
-        # replication, not of English (BASELINE config 4 tiles 6,520,792 bytes)
-        unit = unit[:262139]
+        from smart_amd import corpus
+        unit = corpus.english_unit()  # the whole corpus as getText loads it, not an excerpt (round 1 tiled 262,139 bytes)
         text = Text.upload_tiled(unit, n)
     else:
         text = Text.generate(SEED, args.sigma, n)
@@ -54,13 +54,14 @@ def main():
     for m in [int(x) for x in args.ms.split(",")]:
         pats = []
         for j in range(args.reps):
-            k = splitmix64(PATTERN_SALT + 4096 * j + m) % (n - m)
+            k = splitmix64(PATTERN_SALT + 4096 * j + m) % ((len(unit) if unit is not None else n) - m)  # English: from the first copy
             pats.append(text.pattern(k, m))
         ref_counts = None
         for algo in args.algos.split(","):
             if m < smart_amd.MIN_M.get(algo, 1):  # the algorithm does not apply (raita.c:37, hash3.c:31, ...)
                 continue
             plans = [Plan(algo, p) for p in pats]
+            kernels = sorted({pl.kernel_name for pl in plans})  # the plan's choice (api.cpp build_blob), per pattern
             plans[0].launch(text, slot=1)  # warm-up
             plans[0].result(1)
             for pl in plans:
@@ -75,10 +76,10 @@ def main():
             gbs = n / (med * 1e-3) / 1e9
             row = {"algo": algo, "m": m, "sigma": args.sigma, "n": n, "kernel_ms_median": round(med, 4),
                    "kernel_ms_min": round(times[0], 4), "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / 8000.0, 4),
-                   "counts": counts, "counts_agree": ok}
+                   "counts": counts, "counts_agree": ok, "kernels": kernels}
             rows.append(row)
-            print("%-5s m=%-5d sigma=%-3d  %8.4f ms (min %8.4f)  %8.1f GB/s  %5.1f%% of 8 TB/s  counts %s %s"
-                  % (algo, m, args.sigma, med, times[0], gbs, gbs / 80.0, counts[:3], "" if ok else "MISMATCH"),
+            print("%-5s m=%-5d sigma=%-3d  %8.4f ms (min %8.4f)  %8.1f GB/s  %5.1f%% of 8 TB/s  counts %s %s [%s]"
+                  % (algo, m, args.sigma, med, times[0], gbs, gbs / 80.0, counts[:3], "" if ok else "MISMATCH", "+".join(kernels)),
                   flush=True)
             for pl in plans:
                 pl.free()
