@@ -1100,6 +1100,25 @@ __device__ __forceinline__ uint32_t lshl_or_now(uint32_t a, uint32_t b)
     return r;
 }
 
+// so_runs, LONG: the hits of one 16-byte chunk (bit 15-q of hm: the w-byte prefix ends at byte base + q of the
+// run).  The first one of a half is parked for wave_verify (its offset in the run; 0 = none), further ones —
+// rare — are completed by the lane itself.  Out of line: inlined (four times) its loads and loops cost the
+// streaming path of the long-pattern instantiation 20+ VGPRs and spills.
+// Returns (hits counted << 32) | parked offset: by value, so that the caller's copy stays in a register.
+static __device__ __attribute__((noinline)) uint64_t so_long_hits(const uint8_t* run_text, const uint8_t* tail, uint32_t len,
+                                                                  uint32_t base, uint32_t hm, uint32_t parked_off)
+{
+    uint32_t n = 0;
+    while (hm) {
+        const uint32_t bit = 31u - __builtin_clz(hm);
+        hm &= ~(1u << bit);
+        const uint32_t off = base + (15u - bit) + 1;  // the byte after the prefix = start + w
+        if (parked_off == 0) parked_off = off;
+        else n += global_equal(run_text + off, tail, len);
+    }
+    return ((uint64_t)n << 32) | parked_off;
+}
+
 template <bool LONG>  // LONG: m > 29, hits of the 29-byte prefix are verified
 __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns, const ScanArgs* __restrict__ batch)
 {
@@ -1111,22 +1130,6 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
     const RunIo io = swap_io(smem + 65536 + wave * kLineSlab, lane, run_len);
     const uint32_t sh = 29u - w;
     const uint32_t sentinel = (0xFFFFFFFFu << sh) & 0x1FFFFFFFu;  // mask of a byte outside the lane's range
-    // the first line of the wave's first group is requested before the table is built: its HBM latency
-    // passes while the workgroup fills the LDS
-    uint4 n0, n1, n2, n3, n4, n5, n6, n7;
-    bool fetched = false;
-    {
-        const uint64_t g = first_group(nruns, 64, kRunWaves, threadIdx.x >> 6);
-        if (g * 64 < nruns) {
-            const RunIo io0 = swap_io(smem, threadIdx.x & 63u, run_len);  // only loff is used
-            const uint8_t* const gbase = a.text + (a.s_begin / run_len + g * 64) * run_len + io0.loff;
-            uint32_t blk[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) blk[i] = g * 64 + 8 * i < nruns ? 8u * i * run_len : 0u;
-            LINE_FETCH(gbase, blk, 0u);
-            fetched = true;
-        }
-    }
     {   // expand the 256 masks to one copy per lane through a 1 KB staging area (wave 0's slab)
         uint32_t* stage = reinterpret_cast<uint32_t*>(smem + 65536);
         if (threadIdx.x < 256)
@@ -1160,29 +1163,21 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
         const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
         const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
 
-        if (!fetched) LINE_FETCH(gbase, blk, 0u);
-        fetched = false;
+        uint4 n0, n1, n2, n3, n4, n5, n6, n7;
+        LINE_FETCH(gbase, blk, 0u);
         uint32_t D = 0xFFFFFFFFu << sh;  // no prefix matched yet
-        bool parked = false;
-        const uint8_t* parked_at = a.text;
+        // LONG: the first prefix hit of a half waits here for wave_verify, as its offset in the run (0 = none: a
+        // hit's offset is at least w); the run's text offset is recomputed there — nothing 64-bit stays live
+        uint32_t parked_off = 0;
         // one 64-byte half of a line: the bytes [jb, jb + 64) of every run are in the slab
         auto half = [&](const uint32_t jb) {
             // hit mask of one 16-byte chunk (bit 15-q: a window ends at byte q)
             auto take_hits = [&](uint32_t base, uint32_t hm) {
-                if (!LONG) {
-                    hits += __popc(hm);
-                } else {
-                    while (hm) {  // the prefix matched, ending at byte q: verify P[w..m)
-                        const uint32_t bit = 31u - __builtin_clz(hm);
-                        hm &= ~(1u << bit);
-                        const uint8_t* rest = a.text + seg + base + (15u - bit) + 1;
-                        if (!parked) {
-                            parked = true;
-                            parked_at = rest;
-                        } else {
-                            hits += global_equal(rest, a.blob + w, m - w);
-                        }
-                    }
+                if (!LONG) hits += __popc(hm);
+                else if (hm) {
+                    const uint64_t r = so_long_hits(a.text + (run_first + my) * run_len, a.blob + w, m - w, base, hm, parked_off);
+                    hits += (uint32_t)(r >> 32);
+                    parked_off = (uint32_t)r;
                 }
             };
             if (jb >= j0 && jb + 64u <= jend) {
@@ -1218,12 +1213,12 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t hm = ~H[h];
-                    if (!LONG) {
-                        hits += __popc(hm);
-                    } else {
+                if (!LONG) {
+                    hits += __popc(~H[0]) + __popc(~H[1]);
+                } else if (__any((H[0] & H[1]) != 0xFFFFFFFFu)) {  // rare: ONE wave-uniform branch per half on the streaming path
+#pragma unroll 1
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t hm = ~(h ? H[1] : H[0]);
                         take_hits(jb + 32u * h, hm >> 16);
                         take_hits(jb + 32u * h + 16u, hm & 0xFFFFu);
                     }
@@ -1247,9 +1242,9 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
                     take_hits(base, ~H & 0xFFFFu);
                 }
             }
-            if (LONG && __any(parked)) {  // keep at most one parked window per lane
-                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
-                parked = false;
+            if (LONG && __any(parked_off != 0)) {  // wave-uniform point; at most one parked window per lane
+                hits += wave_verify(parked_off != 0, a.text + (run_first + my) * run_len + parked_off, a.blob + w, m - w);
+                parked_off = 0;
             }
         };
         for (uint32_t k = 0; k < nlines; ++k) {
@@ -1338,22 +1333,6 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     const uint32_t idw = w < 63 ? 4 * w : 254u, Z = idw + 1;
     const uint32_t table_bytes = (Z + 1) * 256;
     const RunIo io = RUNIO ? run_io(smem + table_bytes + wave * kLineSlab, lane, run_len) : swap_io(smem + table_bytes + wave * kLineSlab, lane, run_len);
-    // the first line of the wave's first group is requested before the table is built: its HBM latency
-    // passes while the workgroup fills the LDS
-    uint4 n0, n1, n2, n3, n4, n5, n6, n7;
-    bool fetched = false;
-    {
-        const uint64_t g = first_group(nruns, 64, kRunWaves, threadIdx.x >> 6);
-        if (g * 64 < nruns) {
-            const RunIo io0 = RUNIO ? run_io(smem, threadIdx.x & 63u, run_len) : swap_io(smem, threadIdx.x & 63u, run_len);  // only loff is used
-            const uint8_t* const gbase = a.text + (a.s_begin / run_len + g * 64) * run_len + io0.loff;
-            uint32_t blk[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) blk[i] = g * 64 + (RUNIO ? 16 : 8) * i < nruns ? (RUNIO ? 16u : 8u) * i * run_len : 0u;
-            if (RUNIO) RUN_FETCH(gbase, blk, 0u); else LINE_FETCH(gbase, blk, 0u);
-            fetched = true;
-        }
-    }
     {
         const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
         uint4* t = reinterpret_cast<uint4*>(smem);
@@ -1384,8 +1363,8 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
         const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
 
-        if (!fetched) { if (RUNIO) RUN_FETCH(gbase, blk, 0u); else LINE_FETCH(gbase, blk, 0u); }
-        fetched = false;
+        uint4 n0, n1, n2, n3, n4, n5, n6, n7;
+        if (RUNIO) RUN_FETCH(gbase, blk, 0u); else LINE_FETCH(gbase, blk, 0u);
         uint32_t st = 0;
         bool dense = false;   // wave-uniform: many lanes saw an occurrence end in the last whole half
         bool parked = false;  // PREFIX: first unverified prefix hit of this step
