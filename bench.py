@@ -235,7 +235,7 @@ def main():
     # The plans above were built with the GPU idle (host table construction, small copies): bring the chip back
     # to its working clocks before the W warm-up steps, or a short timed region measures the ramp, not the scan
     # (20 steps = 3 ms; observed: 0.173 ms per step right after an idle phase, 0.156 ms in steady state).
-    PREWARM_PASSES = 200  # streaming reads of the resident text, ~30 ms; not steps, nothing of the timed work
+    PREWARM_PASSES = 64   # streaming reads of the resident text, ~10 ms; not steps, nothing of the timed work
     engine.probe_read_gbs(text, reps=PREWARM_PASSES)
     barrier()
     run(0, W)

@@ -838,7 +838,7 @@ int batch_upload(DeviceCtx* d, int algo, const uint8_t* const* P, uint32_t m, ui
         plans[k].off = total;
         total += blobs[k].size();  // multiples of 256
     }
-    if (!batch_reserve(d, total + 256 + K * sizeof(sg::ScanArgs), K)) return SMARTGPU_ERR_NOMEM;
+    if (!batch_reserve(d, total + 256 + K * sizeof(sg::BatchItem), K)) return SMARTGPU_ERR_NOMEM;
     const double t_up = now_ms();
     // pinned staging -> arena, as many blobs per copy as the staging buffer holds
     for (uint32_t k = 0; k < K;) {
@@ -915,18 +915,25 @@ int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, u
     std::vector<uint32_t> order(K);
     for (uint32_t k = 0; k < K; ++k) order[k] = k;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
-    sg::ScanArgs* host_items = reinterpret_cast<sg::ScanArgs*>(d->pinned);
-    for (uint32_t i = 0; i < K; ++i)
-        host_items[i] = sg::prepare_scan_args(algo, batch_args(plans[order[i]], d, m, text, off, n, d->batch_counts + order[i]));
-    sg::ScanArgs* dev_items = reinterpret_cast<sg::ScanArgs*>(d->arena + d->arena_bytes - ((static_cast<size_t>(K) * sizeof(sg::ScanArgs) + 255) & ~size_t(255)));
-    HIP_TRY(hipMemcpyAsync(dev_items, host_items, static_cast<size_t>(K) * sizeof(sg::ScanArgs), hipMemcpyHostToDevice, d->stream),
+    sg::BatchItem* host_items = reinterpret_cast<sg::BatchItem*>(d->pinned);
+    for (uint32_t i = 0; i < K; ++i) {
+        const BatchPlan& bp = plans[order[i]];
+        const sg::ScanArgs pa = sg::prepare_scan_args(algo, batch_args(bp, d, m, text, off, n, d->batch_counts));
+        host_items[i] = sg::BatchItem{bp.off, order[i], pa.halo, pa.fp_off, pa.prefer_packed, pa.sparse, pa.so_off};
+    }
+    sg::BatchItem* dev_items = reinterpret_cast<sg::BatchItem*>(d->arena + d->arena_bytes - ((static_cast<size_t>(K) * sizeof(sg::BatchItem) + 255) & ~size_t(255)));
+    HIP_TRY(hipMemcpyAsync(dev_items, host_items, static_cast<size_t>(K) * sizeof(sg::BatchItem), hipMemcpyHostToDevice, d->stream),
             return SMARTGPU_ERR_HIP);
     uint32_t ev = 0;
     if (timed) HIP_TRY(hipEventRecord(d->batch_events[ev++], d->stream), return SMARTGPU_ERR_HIP);
     for (uint32_t i = 0; i < K;) {
         uint32_t j = i;
         while (j < K && key(order[j]) == key(order[i])) ++j;
-        HIP_TRY(sg::launch_scan_set(algo, host_items[i], dev_items + i, j - i, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
+        // the set's common arguments: blob = arena base, count = first slot (the items add their own), and the
+        // group's plan fields, which choose kernel and grid
+        sg::ScanArgs first = batch_args(plans[order[i]], d, m, text, off, n, d->batch_counts);
+        first.blob = d->arena;
+        HIP_TRY(sg::launch_scan_set(algo, first, dev_items + i, j - i, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
         if (timed) HIP_TRY(hipEventRecord(d->batch_events[ev++], d->stream), return SMARTGPU_ERR_HIP);
         if (groups_out) groups_out->push_back({i, j - i});
         i = j;

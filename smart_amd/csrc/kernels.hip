@@ -43,6 +43,35 @@ namespace sg {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
 
+// The arguments of this workgroup: the by-value set of a single launch, or — a pattern set in one grid
+// (launch_scan_set) — that set with the per-pattern fields of element blockIdx.y of the set's item array: where
+// the pattern's tables sit in the arena, which count slot is its own, and what its plan decided.  The pointers
+// stay derived from the kernel arguments (base + offset), so the compiler keeps treating them as global memory
+// and the values as scalars.  (Selecting between a by-value ScanArgs and one loaded from memory made every
+// load of the kernels a flat_load and moved their address arithmetic to the vector unit: packed_scan 12-15 % slower.)
+__device__ __forceinline__ ScanArgs pick_args(const ScanArgs& a1, const BatchItem* __restrict__ batch)
+{
+    ScanArgs a = a1;
+    if (batch) {
+        constexpr int W = sizeof(BatchItem) / 4;
+        static_assert(sizeof(BatchItem) == 32, "BatchItem is copied word by word");
+        uint32_t w[W];
+        __builtin_memcpy(w, batch + blockIdx.y, sizeof(BatchItem));
+#pragma unroll
+        for (int i = 0; i < W; ++i) w[i] = __builtin_amdgcn_readfirstlane(w[i]);
+        BatchItem it;
+        __builtin_memcpy(&it, w, sizeof(BatchItem));
+        a.blob = a1.blob + it.blob_off;
+        a.count = a1.count + it.count_idx;
+        a.halo = it.halo;
+        a.fp_off = it.fp_off;
+        a.prefer_packed = it.prefer_packed;
+        a.sparse = it.sparse;
+        a.so_off = it.so_off;
+    }
+    return a;
+}
+
 // 16-byte load of text that is read once: non-temporal (global_load_dwordx4 ... nt).
 // Measured with tools/probe/read_bw.hip on MI355X: a coalesced streaming read reaches
 // 7.0-7.1 TB/s with nt loads against 6.2-6.3 TB/s with the default cache policy.
@@ -201,9 +230,9 @@ static __device__ __forceinline__ void tile_park(uint8_t* txt, uint32_t i0, cons
 //      of the pattern's last q-gram) is the flag, stored with the shift applied after a candidate
 template <int THREADS, int L, bool LONG, int VAR>  // LONG: m-1 > back halo, windows are completed in HBM
 __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a1, uint64_t tile_first,
-                                                    uint32_t ntiles, const ScanArgs* __restrict__ batch)
+                                                    uint32_t ntiles, const BatchItem* __restrict__ batch)
 {
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, H = a.halo, H16 = round16(H);
@@ -341,9 +370,9 @@ __device__ __forceinline__ uint32_t bp_addr(uint32_t P)
 // be subtracted; an equal hash is confirmed byte by byte (LDS through the halo, then memory).
 template <bool KR>
 __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a1, uint64_t tile_first,
-                                                          uint32_t ntiles, const ScanArgs* __restrict__ batch)
+                                                          uint32_t ntiles, const BatchItem* __restrict__ batch)
 {
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = kBpThreads * kBpL;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, H = a.halo, H16 = round16(H);
@@ -523,9 +552,9 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a1, uint64_t 
 // ---------------------------------------------------------------------------
 template <int THREADS, int L, bool LONG>  // LONG: m-1 > back halo
 __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_first,
-                                                   uint32_t ntiles, const ScanArgs* __restrict__ batch)
+                                                   uint32_t ntiles, const BatchItem* __restrict__ batch)
 {
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, H = a.halo, H16 = round16(H);
@@ -653,9 +682,9 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_fi
 // after the fingerprint.
 template <int THREADS, int L, bool LONG, bool SIMPLE>  // LONG: m > 32, prefix hits are verified
 __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_first,
-                                                     uint32_t ntiles, const ScanArgs* __restrict__ batch)
+                                                     uint32_t ntiles, const BatchItem* __restrict__ batch)
 {
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32, H16 = 32;
@@ -789,9 +818,9 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
 // LDS: u32 B[256][W] | P[0..w) | text [tile0-256, tile0+TB)
 // ---------------------------------------------------------------------------
 template <int THREADS, int L, int W, bool LONG>  // LONG: m > kBndmlWindow
-__global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a1, uint64_t tile_first, uint32_t ntiles, const ScanArgs* __restrict__ batch)
+__global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a1, uint64_t tile_first, uint32_t ntiles, const BatchItem* __restrict__ batch)
 {
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     constexpr uint32_t H16 = 256;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1120,9 +1149,9 @@ static __device__ __attribute__((noinline)) uint64_t so_long_hits(const uint8_t*
 }
 
 template <bool LONG>  // LONG: m > 29, hits of the 29-byte prefix are verified
-__global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns, const ScanArgs* __restrict__ batch)
+__global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns, const BatchItem* __restrict__ batch)
 {
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < kSoWindow ? m : kSoWindow;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1323,9 +1352,9 @@ __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base,
 // 0.200-0.210; the full 64 KB table (63+ states) 0.220 against 0.210 — the launcher picks by table size.
 template <bool PREFIX, bool RUNIO>  // PREFIX: m > 254 — the automaton of the 254-byte prefix; hits are verified
 __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
-                                                           uint32_t dfa_off, const ScanArgs* __restrict__ batch)
+                                                           uint32_t dfa_off, const BatchItem* __restrict__ batch)
 {
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1561,9 +1590,9 @@ static __device__ __attribute__((noinline)) uint32_t epsm_verify(const uint8_t* 
 // EPSM and packed_scan<256, 4, 0, ..> for Horspool's short-pattern regime).
 template <int THREADS, int ROWS, int ALGO, int MODE, int POLICY>
 __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row_first,
-                                                       uint64_t nrows, const ScanArgs* __restrict__ batch)
+                                                       uint64_t nrows, const BatchItem* __restrict__ batch)
 {
-    const ScanArgs a = batch ? batch[blockIdx.y] : a1;  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     // POLICY 0: A non-temporal, B cached (default); 1: both cached; 3: one nt load + shuffle.
     // (Both loads nt measured 62-67 %: the second load must find the line still cached.  A
     // ballot/SGPR formulation of the first-dword test measured 59-73 %: scalar-unit bound.)
@@ -1800,7 +1829,7 @@ namespace {
 struct TileRange { uint64_t first; uint32_t count; };
 // A pattern set in ONE grid: while set, every scan launch uses gridDim.y = count and hands the kernels the
 // device array of per-pattern arguments (they take argument set blockIdx.y instead of the by-value one).
-struct BatchCtx { const ScanArgs* items; uint32_t count; };
+struct BatchCtx { const BatchItem* items; uint32_t count; };
 thread_local BatchCtx g_batch = {nullptr, 1};
 
 // tiles of `tb` absolute offsets intersecting [lo, hi)
@@ -2332,7 +2361,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_scan_set(int algo, const ScanArgs& first, const ScanArgs* device_items, uint32_t count, int num_cus,
+hipError_t launch_scan_set(int algo, const ScanArgs& first, const BatchItem* device_items, uint32_t count, int num_cus,
                            hipStream_t stream)
 {
     if (count == 0) return hipSuccess;

@@ -41,6 +41,14 @@ struct ScanArgs {
     unsigned long long* count;  // device result slot (pre-zeroed)
 };
 
+// One pattern of a set that runs as ONE grid (launch_scan_set): what differs from pattern to pattern.  Everything
+// else — text, range, m — and the BASES of the table arena and of the count array come from the by-value ScanArgs.
+struct BatchItem {
+    uint64_t blob_off;       // the pattern's blob inside the arena (ScanArgs.blob = arena base)
+    uint32_t count_idx;      // its count slot (ScanArgs.count = first slot)
+    uint32_t halo, fp_off, prefer_packed, sparse, so_off;  // as in ScanArgs, after prepare_scan_args
+};
+
 // Byte offsets of the tables inside the blob, after the pattern slot.
 //  HOR : u16 tab[256]   shift | 0x8000 if c == P[m-1]; u8 tab8[256]; fingerprint (as EPSM)
 //  BM  : u16 first[256] (last-byte shift | 0x8000 if c == P[m-1]), u16 second[256] (the same one byte earlier), u16 bc[256], u16 gs[m], u16 safe_shift
@@ -59,10 +67,11 @@ struct LaunchInfo {
 // Enqueue the scan for `algo` on `stream`; returns hipSuccess or the launch error.
 hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream);
 ScanArgs prepare_scan_args(int algo, ScanArgs a);  // what launch_scan fills in (fp_off, so_off of SO/SA)
-// The same for a pattern set in ONE grid (gridDim.y = count): `device_items` holds the per-pattern arguments
-// in device memory; all of them must lead launch_scan to the same kernel and grid as `first` does (same
-// algorithm, m, range, prefer_packed, sparse, so_off != 0) — the caller groups them and has applied prepare_scan_args.
-hipError_t launch_scan_set(int algo, const ScanArgs& first, const ScanArgs* device_items, uint32_t count, int num_cus,
+// The same for a pattern set in ONE grid (gridDim.y = count): `device_items` holds the per-pattern fields in
+// device memory, `first` the common ones with blob = arena base and count = first count slot, plus the first
+// pattern's plan fields (which choose kernel and grid: all patterns of the set must agree on prefer_packed,
+// sparse and so_off != 0 — the caller groups them — and carry prepare_scan_args' fp_off / so_off).
+hipError_t launch_scan_set(int algo, const ScanArgs& first, const BatchItem* device_items, uint32_t count, int num_cus,
                            hipStream_t stream);
 // occurrence positions (extension): appends every s in [a.s_begin, a.s_end) with T[s..s+m) == P to `out`
 // (unordered, at most `cap` entries), total in a.count; the blob must be an EPSM blob

@@ -102,6 +102,8 @@ def _load(path):
     for a in ALGOS:
         sig["smartgpu_%s_search" % a] = (i32, [vp, i32, vp, i32])
     for name, (res, args) in sig.items():
+        if not hasattr(L, name) and os.path.abspath(path) != os.path.join(_HERE, "csrc", "libsmartgpu.so"):
+            continue  # an older build loaded for an A/B run (SMARTGPU_LIB / use_library): it lacks the newer entry points
         f = getattr(L, name)
         f.restype = res
         f.argtypes = args
