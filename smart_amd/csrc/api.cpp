@@ -197,6 +197,7 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
     // and the skip kernels only stream (80-86 % on rand128 against 76-81 %).  Measured: DESIGN.md §8.
     // The count does not depend on the choice.
     bool repeats = false;
+    bool repeats_short = false;  // 7 bytes or fewer with a symbol that occurs twice (a small alphabet, most likely)
     {
         uint32_t cnt[256] = {0};
         for (uint32_t i = 0; i < m; ++i) ++cnt[P[i]];
@@ -205,6 +206,7 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         // m < 32: too few symbols for the estimate; two equal pairs are taken as a sign (rand32, m = 16:
         // skip kernels 58-65 %, packed 76 %; on rand128 one pattern in four then goes packed, 76 % for 83 %)
         repeats = m > 7 && (pairs * 48 > static_cast<uint64_t>(m) * (m - 1) || (m < 32 && pairs >= 4));
+        repeats_short = m <= 7 && pairs >= 2;
     }
     // The opposite case: symbols do not repeat (random text over a large alphabet).  Windows then die on
     // their first comparison and a skip kernel only streams; it runs best with FEWER workgroups per CU
@@ -398,18 +400,31 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             break;
         }
     }
-    // A pattern of 16+ bytes whose first dword says next to nothing about where it occurs (two or
-    // three symbols: every lane of the packed matcher keeps a candidate through all four fingerprint
-    // dwords, every skip is a byte or two) is counted by the Shift-Or runs kernel, which does the
-    // same work whatever the bytes are (kernels.hip launch_scan): append its masks.  The estimate is
-    // the chance that 4 text bytes drawn like the pattern's own equal P[0..4), times the 16
-    // alignments a lane tests.  KMP, SO, SA and KR keep their own serial kernels.
-    if (m >= 16 && algo != SMARTGPU_KMP && algo != SMARTGPU_SO && algo != SMARTGPU_SA && algo != SMARTGPU_KR) {
-        uint32_t cnt[256] = {0};
-        for (uint32_t i = 0; i < m; ++i) ++cnt[P[i]];
-        double pass = 16.0;
-        for (uint32_t i = 0; i < 4; ++i) pass *= static_cast<double>(cnt[P[i]]) / m;
-        if (pass >= 0.15) {  // rand2: 1.0, rand3: 0.2 (so_runs 63-68 % vs 54-63 %), rand4: 0.06 (no difference measured)
+    // Patterns that are counted by the Shift-Or runs kernel whatever the algorithm (kernels.hip launch_scan): their
+    // plans carry its masks as well.
+    //  * Symbols repeat (the rule above; or, for 7 bytes and fewer, some symbol occurs twice): small alphabets,
+    //    natural language, rand32.  Round 1 sent these to the packed matcher, which tests two or three fingerprint
+    //    dwords in most rows there (rand4 64-72 %, English below 32 bytes 70-73 %, rand32 short 72-76 %); so_runs
+    //    does the same work whatever the bytes are and since round 2 runs at 75-81 % on all of them (English from 32
+    //    bytes on: 79-80 % both).  On random text over a large alphabet symbols do not repeat and nothing changes.
+    //  * 16+ bytes whose first dword says next to nothing about where the pattern occurs (two or three symbols:
+    //    every lane of the packed matcher keeps a candidate through all four fingerprint dwords, every skip is a byte
+    //    or two): the chance that 4 text bytes drawn like the pattern's own equal P[0..4), times the 16 alignments a
+    //    lane tests, is 0.15 or more.
+    // KMP, SO, SA and KR keep their own serial kernels, EPSM its packed matcher (it IS that algorithm).
+    if (algo != SMARTGPU_KMP && algo != SMARTGPU_SO && algo != SMARTGPU_SA && algo != SMARTGPU_KR) {
+        // * Short patterns (below the algorithm's measured crossover with its own skip loop, kernels.hip packed_max_m):
+        //   the every-byte kernels win there; so_runs and the packed matcher are equal on rand128 (76-77 %), so_runs
+        //   ahead on everything else (rand256, rand32, English at m = 2, 4: 78-81 % against 67-76 %).
+        bool to_so = (repeats || repeats_short || m <= sg::short_pattern_max_m(algo)) && algo != SMARTGPU_EPSM;
+        if (!to_so && m >= 16) {
+            uint32_t cnt[256] = {0};
+            for (uint32_t i = 0; i < m; ++i) ++cnt[P[i]];
+            double pass = 16.0;
+            for (uint32_t i = 0; i < 4; ++i) pass *= static_cast<double>(cnt[P[i]]) / m;
+            to_so = pass >= 0.15;  // rand2: 1.0, rand3: 0.2 (so_runs 63-68 % vs 54-63 %), rand4: 0.06
+        }
+        if (to_so) {
             blob.resize((blob.size() + 15) & ~size_t(15), 0);
             *so_off = static_cast<uint32_t>(blob.size());
             const std::vector<uint32_t> S = sg::shift_or_masks(P, m);

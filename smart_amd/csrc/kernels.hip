@@ -1901,6 +1901,8 @@ static constexpr uint32_t packed_max_m(int algo)
          : 0u;
 }
 
+uint32_t short_pattern_max_m(int algo) { return packed_max_m(algo); }
+
 // tile shapes (threads, bytes per lane)
 constexpr int kHorT = 256, kHorL = 64;
 constexpr int kBmT = 256, kBmL = 64;

@@ -78,6 +78,8 @@ hipError_t launch_scan_set(int algo, const ScanArgs& first, const BatchItem* dev
 hipError_t launch_find(const ScanArgs& a, unsigned long long* out, unsigned long long cap, int num_cus,
                        hipStream_t stream);
 const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_masks);
+// longest pattern for which a skip algorithm's own LDS-tile loop is slower than an every-byte kernel (0: never)
+uint32_t short_pattern_max_m(int algo);
 
 // tuning knobs (smartgpu_tune): [0] HOR variant 0 auto / 1 flat / 2 bank-private
 extern int g_tune[8];

@@ -177,24 +177,26 @@ def test_kernel_choice_follows_the_pattern(oracle):
         assert kf("hor", rnd[:m]) == "hor_scan" and kf("bm", rnd[:m]) == "bm_scan" and kf("bndm", rnd[:m]) == "bndm_scan"
         assert kf("bndml", rnd[:m]) == ("bndm_scan" if m <= 32 else "bndml_scan")
         assert kf("kr", rnd[:m]) == "hor_scan_bp"
-    # short patterns: the packed matcher (crossovers per algorithm)
-    assert kf("hor", rnd[:7]) == "packed_scan" and kf("hor", rnd[100:108]) in ("hor_scan", "packed_scan")
-    assert kf("bm", rnd[:7]) == "packed_scan" and kf("bndm", rnd[:10]) == "packed_scan" and kf("kr", rnd[:15]) == "packed_scan"
-    # natural language, DNA-like alphabets: symbols repeat -> packed matcher at any m
+    # short patterns (crossovers per algorithm): the Shift-Or runs kernel (round 1: the packed matcher, which Karp-Rabin keeps)
+    assert kf("hor", rnd[:7]) == "so_runs" and kf("hor", rnd[100:108]) in ("hor_scan", "so_runs")
+    assert kf("bm", rnd[:7]) == "so_runs" and kf("bndm", rnd[:10]) == "so_runs" and kf("kr", rnd[:15]) == "packed_scan"
+    # natural language, DNA-like alphabets: symbols repeat -> the Shift-Or runs kernel at any m (round 1: packed matcher)
     for m in (16, 64, 1024):
         for a in ("hor", "bm", "bndm", "qs", "raita", "hash3", "sbndm", "bndml", "tunedbm"):
-            assert kf(a, eng[200:200 + m]) == "packed_scan", (a, m)
-            assert kf(a, four[:m]) in ("packed_scan", "so_runs"), (a, m)  # so_runs when its first four symbols are the frequent ones
-    # two symbols, 16+ bytes: the bit-parallel runs kernel, whatever the algorithm (KMP and KR keep their own)
+            assert kf(a, eng[200:200 + m]) == "so_runs", (a, m)
+            assert kf(a, four[:m]) == "so_runs", (a, m)
+    assert kf("hor", b"abca") == "so_runs" and kf("bm", four[:4]) == "so_runs" and kf("hor", b"abcd") == "so_runs"
+    # two symbols, 16+ bytes: the bit-parallel runs kernel, whatever the algorithm (KMP and KR keep their own, EPSM is
+    # the packed matcher except on patterns its first dword cannot tell apart)
     for m in (16, 33, 300):
         for a in engine.ALGOS:
             want = {"kmp": "kmp_runs", "kr": "hor_scan_bp"}.get(a, "so_runs")
             assert kf(a, two[:m]) == want, (a, m)
-    assert kf("hor", two[:12]) == "packed_scan"
+    assert kf("hor", two[:12]) == "so_runs" and kf("epsm", two[:12]) == "packed_scan"
     # the serial automata never move
     for P in (rnd[:32], eng[:32], four[:32]):
         assert kf("kmp", P) == "kmp_runs" and kf("so", P) == "so_runs" and kf("sa", P) == "so_runs"
-    assert kf("epsm", rnd[:32]) == "packed_scan" and kf("epsm", eng[:32]) == "packed_scan"
+    assert kf("epsm", rnd[:32]) == "packed_scan" and kf("epsm", eng[:32]) == "packed_scan"  # EPSM is the packed matcher
     # tune(0,1): every algorithm on its own kernel
     engine.tune(0, 1)
     try:

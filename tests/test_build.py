@@ -42,3 +42,16 @@ def test_no_product_kernel_uses_scratch():
     assert len(runs) == 5, sorted(runs)
     for k, v in runs.items():
         assert v["vgprs"] <= 128, (k, v)
+
+
+def test_kernels_load_the_text_with_global_instructions(tmp_path):
+    """Text and table pointers must stay recognisable as global memory: a kernel whose pointers lose that
+    (round 2: a select between two argument structs) loads with flat_load and computes addresses on the vector
+    unit — packed_scan ran 12-15 % slower.  A handful of flat loads remain in rarely taken verification code."""
+    asm = tmp_path / "kernels.s"
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+                        "-o", str(asm), os.path.join(CSRC, "kernels.hip")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = asm.read_text()
+    flat, glob = len(re.findall(r"\bflat_load", text)), len(re.findall(r"\bglobal_load", text))
+    assert glob > 300 and flat < 0.1 * glob, (flat, glob)
