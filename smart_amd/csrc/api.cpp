@@ -411,12 +411,13 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
     //    every lane of the packed matcher keeps a candidate through all four fingerprint dwords, every skip is a byte
     //    or two): the chance that 4 text bytes drawn like the pattern's own equal P[0..4), times the 16 alignments a
     //    lane tests, is 0.15 or more.
-    // KMP, SO, SA and KR keep their own serial kernels, EPSM its packed matcher (it IS that algorithm).
-    if (algo != SMARTGPU_KMP && algo != SMARTGPU_SO && algo != SMARTGPU_SA && algo != SMARTGPU_KR) {
+    // KMP, SO and SA keep their own serial kernels, Karp-Rabin its own from 16 bytes on, EPSM its packed matcher
+    // (it IS that algorithm).
+    if (algo != SMARTGPU_KMP && algo != SMARTGPU_SO && algo != SMARTGPU_SA && (algo != SMARTGPU_KR || m < 16)) {
         // * Short patterns (below the algorithm's measured crossover with its own skip loop, kernels.hip packed_max_m):
         //   the every-byte kernels win there; so_runs and the packed matcher are equal on rand128 (76-77 %), so_runs
         //   ahead on everything else (rand256, rand32, English at m = 2, 4: 78-81 % against 67-76 %).
-        bool to_so = (repeats || repeats_short || m <= sg::short_pattern_max_m(algo)) && algo != SMARTGPU_EPSM;
+        bool to_so = algo == SMARTGPU_KR ? true : (repeats || repeats_short || m <= sg::short_pattern_max_m(algo)) && algo != SMARTGPU_EPSM;
         if (!to_so && m >= 16) {
             uint32_t cnt[256] = {0};
             for (uint32_t i = 0; i < m; ++i) ++cnt[P[i]];

@@ -1901,7 +1901,12 @@ static constexpr uint32_t packed_max_m(int algo)
          : 0u;
 }
 
-uint32_t short_pattern_max_m(int algo) { return packed_max_m(algo); }
+uint32_t short_pattern_max_m(int algo)
+{
+    if (algo == SMARTGPU_SBNDM || algo == SMARTGPU_BNDML) return packed_max_m(SMARTGPU_BNDM);  // they share bndm_scan's crossover
+    if (algo == SMARTGPU_KR) return 15;  // below 16 bytes only the low m bits of the rolled hash can be compared (launch_scan)
+    return packed_max_m(algo);
+}
 
 // tile shapes (threads, bytes per lane)
 constexpr int kHorT = 256, kHorL = 64;

@@ -177,9 +177,9 @@ def test_kernel_choice_follows_the_pattern(oracle):
         assert kf("hor", rnd[:m]) == "hor_scan" and kf("bm", rnd[:m]) == "bm_scan" and kf("bndm", rnd[:m]) == "bndm_scan"
         assert kf("bndml", rnd[:m]) == ("bndm_scan" if m <= 32 else "bndml_scan")
         assert kf("kr", rnd[:m]) == "hor_scan_bp"
-    # short patterns (crossovers per algorithm): the Shift-Or runs kernel (round 1: the packed matcher, which Karp-Rabin keeps)
+    # short patterns (crossovers per algorithm): the Shift-Or runs kernel (round 1: the packed matcher)
     assert kf("hor", rnd[:7]) == "so_runs" and kf("hor", rnd[100:108]) in ("hor_scan", "so_runs")
-    assert kf("bm", rnd[:7]) == "so_runs" and kf("bndm", rnd[:10]) == "so_runs" and kf("kr", rnd[:15]) == "packed_scan"
+    assert kf("bm", rnd[:7]) == "so_runs" and kf("bndm", rnd[:10]) == "so_runs" and kf("kr", rnd[:15]) == "so_runs" and kf("sbndm", rnd[:10]) == "so_runs"
     # natural language, DNA-like alphabets: symbols repeat -> the Shift-Or runs kernel at any m (round 1: packed matcher)
     for m in (16, 64, 1024):
         for a in ("hor", "bm", "bndm", "qs", "raita", "hash3", "sbndm", "bndml", "tunedbm"):
