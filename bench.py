@@ -364,8 +364,8 @@ def main():
                        "text_bytes_per_gpu": local_len, "patterns": K,
                        "corpus": ("counter-based splitmix64 rand-sigma, seed 0x5EED0001, generated on device" if english is None
                                   else "bible.txt||world192.txt as getText loads it (smart.c:95-138), tiled on device"),
-                       "sharding": ("byte offset, (m-1) overlap, one RCCL all-reduce of the K counts over %d ranks (%s)"
-                                    % (world, args.backend)) if world > 1 else "single GPU",
+                       "sharding": ("byte offset, (m-1) overlap, one all-reduce of the K counts over %d ranks (%s)"
+                                    % (world, "RCCL" if args.backend == "nccl" else args.backend + ", rehearsal")) if world > 1 else "single GPU",
                        "ranks": world,
                        "pre_ms_per_pattern": round(pre_ms, 4),
                        "prewarm": "%d streaming-read passes over the text before the warm-up steps (clocks), untimed" % PREWARM_PASSES},

@@ -59,6 +59,30 @@ def test_fuzz_vectors(oracle):
             assert got[a] == r["count"], (a, r, got)
 
 
+def test_fuzz_vectors_every_algorithm_on_its_own_kernel(oracle):
+    """The plans send short patterns and patterns whose symbols repeat to so_runs (api.cpp build_blob); with
+    smartgpu_tune(0,1) every algorithm counts on its own kernel — hor_scan, bm_scan, bndm_scan, bndml_scan,
+    hor_scan_bp — for every fuzz vector (small alphabets, periodic texts, m = 1 .. 300), and with (0,3) the skip
+    algorithms count on the packed matcher."""
+    from smart_amd import engine
+    rows = load_golden("fuzz_vectors.json")["rows"]
+    for setting, algos, step in ((1, ALGOS, 1), (3, ("hor", "bm", "bndm", "qs", "raita", "hash3", "sbndm", "bndml", "tunedbm"), 3)):
+        engine.tune(0, setting)
+        try:
+            for r in rows[::step]:
+                P, T = fuzz_case(oracle, r)
+                text = Text.upload(T)
+                got = gpu_counts(P, text, algos=algos)
+                text.free()
+                for a in got:
+                    assert got[a] == r["count"], (setting, a, r, got)
+            if setting == 1:
+                P = oracle.gen_text(3, 4, 0, 64)
+                assert smart_amd.kernel_for("bm", P) == "bm_scan" and smart_amd.kernel_for("hor", P[:5]) == "hor_scan"
+        finally:
+            engine.tune(0, 0)
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3])
 def test_horspool_variants(oracle, ab_library, variant):
     """All Horspool regimes (flat LDS tile / bank-private layout / packed) on the fuzz
