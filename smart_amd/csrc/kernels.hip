@@ -1323,6 +1323,38 @@ __device__ __forceinline__ void kmp_chunk_fast(const uint4& v, uint32_t& st)
     for (int q = 0; q < 16; ++q) st = kmp_delta(d[q >> 2], st, q & 3);
 }
 
+// Sixteen transitions, four at a time where the whole WAVE is in state 0.  kmp.c:57-60 in state 0 compares the
+// byte with P[0] (kmpNext[0] = -1); four bytes on from state 0 the automaton is in the state of the longest
+// prefix of P that ends the dword: 4 if the dword is P[0..4), else 3 if its last three bytes are P[0..3), ... —
+// four compares and four selects, no lookup, no wait.  On text over a large alphabet nearly every lane is in
+// state 0 nearly always ((127/128)^64 = 60 % of the dword boundaries of a wave on rand128, 78 % on rand256), so
+// z0 — wave-uniform: every lane is in state 0 — holds for most dwords; otherwise the four lookups.  Needs w >= 5
+// (the states 1..4 are plain states with ids 4, 8, 12, 16 in both numberings, and no occurrence can end inside
+// the dword).  nfast counts the dwords that went without lookups (the caller turns this form off where it does
+// not pay: small alphabets, natural language — there z0 practically never holds).
+struct KmpPrefix4 { uint32_t p4, p3, p2, p1; };  // P[0..4) as a dword, P[0..3) << 8, P[0..2) << 16, P[0] << 24
+
+__device__ __forceinline__ void kmp_chunk_skip4(const uint4& v, uint32_t& st, bool& z0, const KmpPrefix4& pf, uint32_t& nfast)
+{
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (z0) {
+            const uint32_t x = d[k];
+            uint32_t s = (x & 0xFF000000u) == pf.p1 ? 4u : 0u;       // the last byte is P[0]: state 1 (id 4)
+            s = (x & 0xFFFF0000u) == pf.p2 ? 8u : s;                 // the last two are P[0..2): state 2
+            s = (x & 0xFFFFFF00u) == pf.p3 ? 12u : s;                // the last three are P[0..3): state 3
+            s = x == pf.p4 ? 16u : s;                                // all four: state 4
+            st = s;
+            ++nfast;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st = kmp_delta(d[k], st, q);
+        }
+        z0 = __ballot(st != 0u) == 0;
+    }
+}
+
 // sixteen transitions, counting (MASK: collecting) the entries into Z; CHECK: only bytes j0 <= j < jend
 template <bool CHECK, bool MASK>
 __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
@@ -1347,9 +1379,12 @@ __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base,
     }
 }
 
-// RUNIO: the half-line loader of kmp_runs1 (default cache policy) instead of the swap loader.  Measured
-// (profiles/r02, same box, 1 GiB rand128): tables below 64 KB 0.194-0.201 ms behind the swap loader against
-// 0.200-0.210; the full 64 KB table (63+ states) 0.220 against 0.210 — the launcher picks by table size.
+// RUNIO: the half-line loader of kmp_runs1 (default cache policy) instead of the swap loader.  Measured together with
+// the wave-wide state-0 form (kmp_chunk_skip4), alternating on one box, ms per GiB of rand128:
+//   m <= 32 (tables up to 33 KB): swap loader 0.194-0.199, + state-0 form 0.183-0.187;
+//   m = 64 (full 64 KB table):    half-line 0.206-0.210, swap 0.197-0.199, swap + state-0 form 0.186-0.189;
+//   m = 256, 1024 (PREFIX):       half-line 0.208-0.213, swap 0.206-0.212, either + state-0 form 0.218-0.232.
+// So: patterns up to 254 bytes run <false, false> with the state-0 form, longer ones <true, true> without it.
 template <bool PREFIX, bool RUNIO>  // PREFIX: m > 254 — the automaton of the 254-byte prefix; hits are verified
 __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
                                                            uint32_t dfa_off, const BatchItem* __restrict__ batch)
@@ -1361,6 +1396,14 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     const uint32_t w = PREFIX ? kKmpWindow : m;  // length the automaton recognises
     const uint32_t idw = w < 63 ? 4 * w : 254u, Z = idw + 1;
     const uint32_t table_bytes = (Z + 1) * 256;
+    KmpPrefix4 pf;
+    {
+        const uint32_t p = *reinterpret_cast<const uint32_t*>(a.blob);  // P[0..4) (the pattern slot is zero-padded)
+        pf.p4 = p;
+        pf.p3 = p << 8;
+        pf.p2 = p << 16;
+        pf.p1 = p << 24;
+    }
     const RunIo io = RUNIO ? run_io(smem + table_bytes + wave * kLineSlab, lane, run_len) : swap_io(smem + table_bytes + wave * kLineSlab, lane, run_len);
     {
         const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
@@ -1395,6 +1438,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         uint4 n0, n1, n2, n3, n4, n5, n6, n7;
         if (RUNIO) RUN_FETCH(gbase, blk, 0u); else LINE_FETCH(gbase, blk, 0u);
         uint32_t st = 0;
+        bool skip4 = !PREFIX && w >= 5;  // wave-uniform: the wave-wide state-0 form pays (kmp_chunk_skip4); probed again every 8 lines
         bool dense = false;   // wave-uniform: many lanes saw an occurrence end in the last whole half
         bool parked = false;  // PREFIX: first unverified prefix hit of this step
         const uint8_t* parked_at = a.text;
@@ -1431,10 +1475,21 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
                 bool seen = false;
                 if (!dense) {
                     uint32_t at[4];  // state before each 16-byte chunk
+                    if (skip4) {
+                        bool z0 = __ballot(st != 0u) == 0;
+                        uint32_t nfast = 0;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        at[q] = st;
-                        kmp_chunk_fast(run_piece(io, q), st);
+                        for (int q = 0; q < 4; ++q) {
+                            at[q] = st;
+                            kmp_chunk_skip4(run_piece(io, q), st, z0, pf, nfast);
+                        }
+                        skip4 = nfast >= 4;  // of 16 dwords: below that the compares cost more than the lookups they save
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            at[q] = st;
+                            kmp_chunk_fast(run_piece(io, q), st);
+                        }
                     }
                     seen = st == Z;
                     if (__any(seen)) {
@@ -1467,6 +1522,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
             }
         };
         for (uint32_t k = 0; k < nlines; ++k) {
+            if ((k & 7u) == 7u) skip4 = !PREFIX && w >= 5;
             if (RUNIO) {
                 RUN_PARK(io, n0, n1, n2, n3);
                 half(k * kRunLine);
@@ -2090,9 +2146,9 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     } else
 #endif
     {
-        // 63+ states: the full 64 KB table, behind the half-line loader (see kmp_runs)
+        // the prefix automaton of patterns beyond 254 bytes: behind the half-line loader, without the wave-wide
+        // state-0 form (measured, see kmp_runs)
         if (m > kKmpWindow) SG_KMP_RUNS((kmp_runs<true, true>), dfa_off);
-        else if (w >= 63) SG_KMP_RUNS((kmp_runs<false, true>), dfa_off);
         else SG_KMP_RUNS((kmp_runs<false, false>), dfa_off);
     }
 #undef SG_KMP_RUNS
