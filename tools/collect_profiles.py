@@ -69,11 +69,18 @@ def main():
                 return r[4]
         return None
 
-    with open(os.path.join(here, "smart_amd", "csrc", "kernels.hip"), "rb") as f:
-        sha = hashlib.sha256(f.read()).hexdigest()
+    # the kernel source the session ran: the sha256 gpu_round.sh took on the box; a session without one is bound
+    # to the COMMITTED kernels.hip (the working tree may have moved on since the call was started)
     commit = subprocess.run(["git", "-C", here, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    dirty = subprocess.run(["git", "-C", here, "status", "--porcelain", "smart_amd/csrc/kernels.hip"], capture_output=True, text=True).stdout.strip()
-    traffic = {"_source": {"kernels_hip_sha256": sha, "commit": commit + ("+uncommitted kernels.hip" if dirty else ""),
+    committed = subprocess.run(["git", "-C", here, "show", "HEAD:smart_amd/csrc/kernels.hip"], capture_output=True).stdout
+    sha_file = os.path.join(src, "kernels_hip.sha256")
+    if os.path.exists(sha_file):
+        sha = open(sha_file).read().split()[0]
+        if sha != hashlib.sha256(committed).hexdigest():
+            commit += " (session ran a kernels.hip that differs from this commit's)"
+    else:
+        sha = hashlib.sha256(committed).hexdigest()
+    traffic = {"_source": {"kernels_hip_sha256": sha, "commit": commit,
                            "summary": f"profiles/{rnd}/{prefix}_bench_pmc_summary.csv"}}
     for algo, kern in (("hor", "hor_scan"), ("kmp", "kmp_runs"), ("so", "so_runs"), ("epsm", "packed_scan")):
         fe, wr = mean(algo, kern, "FETCH_SIZE"), mean(algo, kern, "WRITE_SIZE")
