@@ -164,14 +164,16 @@ smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
     return t;
 }
 
-// Build the device blob (pattern + tables) for (algo, P, m) in a host vector.
-std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t* halo,
-                                uint32_t* prefer_packed, uint32_t* sparse, uint32_t* so_off)
+// Build the device blob (pattern + tables) for (algo, P, m) in `blob` (cleared first; a caller that builds many
+// reuses one vector: fresh memory for every blob of a pattern set cost more in page faults than the tables in work).
+void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t m, uint32_t* halo,
+                uint32_t* prefer_packed, uint32_t* sparse, uint32_t* so_off)
 {
     *prefer_packed = 0;
     *sparse = 0;
     *so_off = 0;
-    std::vector<uint8_t> blob(sg::kPatternBytes, 0);
+    blob.clear();
+    blob.resize(sg::kPatternBytes, 0);
     std::memcpy(blob.data(), P, m);
     auto append = [&blob](const void* p, size_t bytes) {
         const uint8_t* b = static_cast<const uint8_t*>(p);
@@ -269,35 +271,10 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
             append(tab.data(), tab.size() * 2);
             *halo = m - 1;  // forward halo: the automaton re-scans m-1 bytes
             blob.resize((blob.size() + 15) & ~size_t(15), 0);  // the transition table is 16-byte aligned
-            {   // kmp_runs: the automaton over w = min(m, 254) bytes with an ABSORBING accept row Z.  Every
-                // transition into the accept state w leads to Z, Z leads to Z; row id(w) holds the real
-                // delta(w, .).  Z = id(w) + 1 is the largest id in use (the kernel's min(next, id(w)) turns Z
-                // back into the accept state).  Row r is stored XOR-swizzled by r (LDS bank spread on small
-                // alphabets).  Fewer than 63 states: id(s) = 4s, Z = 4w + 1, the table ends there.  Otherwise
-                // id(s) = rotl8(s, 2) — the states a lane is usually in, the low ones, then differ in the bits
-                // that select the bank —, id(w) = 254, Z = 255; rotl8 maps only s = 191 to 254 and only s = 255
-                // to 255, so state 191 (if there is one besides w) takes the slot w gave up.
-                const uint32_t w = std::min<uint32_t>(m, sg::kKmpWindow);
-                const std::vector<uint8_t> dfa = sg::kmp_dfa(P, w);
-                const bool small = w < 63;
-                const uint32_t idw = small ? 4 * w : 254u, Z = idw + 1;
-                auto rot = [](uint32_t st) { return ((st << 2) | (st >> 6)) & 255u; };
-                auto id = [&](uint32_t st) {
-                    if (st == w) return idw;
-                    if (small) return 4 * st;
-                    return (st == 191) ? rot(w) : rot(st);
-                };
-                std::vector<uint8_t> sw((Z + 1) * 256, 0);
-                for (uint32_t st = 0; st <= w; ++st) {
-                    const uint32_t r = id(st);
-                    for (uint32_t c = 0; c < 256; ++c) {
-                        const uint32_t nx = dfa[st * 256 + c];
-                        sw[r * 256 + (c ^ r)] = static_cast<uint8_t>(nx == w ? Z : id(nx));
-                    }
-                }
-                for (uint32_t c = 0; c < 256; ++c) sw[Z * 256 + (c ^ Z)] = static_cast<uint8_t>(Z);
-                append(sw.data(), sw.size());
-            }
+            // kmp_runs: the automaton over w = min(m, 254) bytes with an ABSORBING accept row Z (every transition into
+            // the accept state w leads to Z, Z leads to Z; row id(w) holds the real delta(w, .)), and the table of the
+            // four-bytes-at-a-time forms (tables.cpp)
+            sg::kmp_runs_tables(P, std::min<uint32_t>(m, sg::kKmpWindow), blob);
 #ifdef SMARTGPU_AB
             {   // kmp_runs1 (A/B build): the automaton of P[0..w), w = min(m, 255); state s is row id(s) = rotl8(s, 2),
                 // the accept state row 255 — or row 4w while the ids 4s do not wrap (w < 64) —, the largest id (its
@@ -411,13 +388,14 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
     //    every lane of the packed matcher keeps a candidate through all four fingerprint dwords, every skip is a byte
     //    or two): the chance that 4 text bytes drawn like the pattern's own equal P[0..4), times the 16 alignments a
     //    lane tests, is 0.15 or more.
-    // KMP, SO and SA keep their own serial kernels, Karp-Rabin its own from 16 bytes on, EPSM its packed matcher
-    // (it IS that algorithm).
-    if (algo != SMARTGPU_KMP && algo != SMARTGPU_SO && algo != SMARTGPU_SA && (algo != SMARTGPU_KR || m < 16)) {
+    // SO and SA keep their own serial kernel, KMP its own from 5 bytes on (below that kmp_runs has only its lookup per
+    // byte, and at 2 bytes walks every fourth half twice to count: 54-69 % on rand128 against so_runs' 76-78 %),
+    // Karp-Rabin its own from 16 bytes on, EPSM its packed matcher (it IS that algorithm).
+    if ((algo != SMARTGPU_KMP || m < 5) && algo != SMARTGPU_SO && algo != SMARTGPU_SA && (algo != SMARTGPU_KR || m < 16)) {
         // * Short patterns (below the algorithm's measured crossover with its own skip loop, kernels.hip packed_max_m):
         //   the every-byte kernels win there; so_runs and the packed matcher are equal on rand128 (76-77 %), so_runs
         //   ahead on everything else (rand256, rand32, English at m = 2, 4: 78-81 % against 67-76 %).
-        bool to_so = algo == SMARTGPU_KR ? true : (repeats || repeats_short || m <= sg::short_pattern_max_m(algo)) && algo != SMARTGPU_EPSM;
+        bool to_so = (algo == SMARTGPU_KR || algo == SMARTGPU_KMP) ? true : (repeats || repeats_short || m <= sg::short_pattern_max_m(algo)) && algo != SMARTGPU_EPSM;
         if (!to_so && m >= 16) {
             uint32_t cnt[256] = {0};
             for (uint32_t i = 0; i < m; ++i) ++cnt[P[i]];
@@ -433,6 +411,13 @@ std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t
         }
     }
     blob.resize((blob.size() + 255) & ~size_t(255), 0);
+}
+
+std::vector<uint8_t> build_blob(int algo, const uint8_t* P, uint32_t m, uint32_t* halo,
+                                uint32_t* prefer_packed, uint32_t* sparse, uint32_t* so_off)
+{
+    std::vector<uint8_t> blob;
+    build_blob(blob, algo, P, m, halo, prefer_packed, sparse, so_off);
     return blob;
 }
 
@@ -842,38 +827,44 @@ constexpr uint64_t kOneGridMaxText = 32ull << 20;  // pattern sets over texts up
 int batch_upload(DeviceCtx* d, int algo, const uint8_t* const* P, uint32_t m, uint32_t K, std::vector<BatchPlan>& plans,
                  double* pre_ms)
 {
-    std::vector<std::vector<uint8_t>> blobs(K);
+    static thread_local std::vector<uint8_t> blob;  // one buffer for every pattern of every set
     std::vector<double> host_ms(K, 0.0);
-    size_t total = 0;
     plans.resize(K);
+    // the blobs of one algorithm and one length are equally long (multiples of 256): size the arena from the first
+    if (!P[0]) { set_error("pattern 0 is NULL"); return SMARTGPU_ERR_ARG; }
+    build_blob(blob, algo, P[0], m, &plans[0].halo, &plans[0].prefer_packed, &plans[0].sparse, &plans[0].so_off);
+    const size_t room = d->pinned_bytes - static_cast<size_t>(K) * 4;  // the tail of the staging buffer holds the launch order
+    if (blob.size() > room) { set_error("a table blob of %zu bytes exceeds the staging buffer", blob.size()); return SMARTGPU_ERR_NOMEM; }
+    if (!batch_reserve(d, (blob.size() + 4096) * K + 256 + K * sizeof(sg::BatchItem), K)) return SMARTGPU_ERR_NOMEM;
+    double up_total = 0.0;
+    size_t total = 0, fill = 0, fill_off = 0;  // staging holds `fill` bytes that belong at arena offset fill_off
+    auto flush = [&]() -> bool {
+        if (!fill) return true;
+        const double t_up = now_ms();
+        const bool ok = hipMemcpyAsync(d->arena + fill_off, d->pinned, fill, hipMemcpyHostToDevice, d->stream) == hipSuccess &&
+                        hipStreamSynchronize(d->stream) == hipSuccess;
+        up_total += now_ms() - t_up;
+        fill_off += fill;
+        fill = 0;
+        return ok;
+    };
     for (uint32_t k = 0; k < K; ++k) {
         if (!P[k]) { set_error("pattern %u is NULL", k); return SMARTGPU_ERR_ARG; }
         const double t0 = now_ms();
-        blobs[k] = build_blob(algo, P[k], m, &plans[k].halo, &plans[k].prefer_packed, &plans[k].sparse, &plans[k].so_off);
-        host_ms[k] = now_ms() - t0;
+        if (k) build_blob(blob, algo, P[k], m, &plans[k].halo, &plans[k].prefer_packed, &plans[k].sparse, &plans[k].so_off);
+        if (total + blob.size() + 256 + K * sizeof(sg::BatchItem) > d->arena_bytes) {  // rerouted patterns carry masks the first did not
+            set_error("batch: the table arena (%zu bytes) is too small for this pattern set", d->arena_bytes);
+            return SMARTGPU_ERR_NOMEM;
+        }
+        if (fill + blob.size() > room && !flush()) { set_error("batch: table upload failed (%s)", hipGetErrorString(hipGetLastError())); return SMARTGPU_ERR_HIP; }
+        std::memcpy(d->pinned + fill, blob.data(), blob.size());  // straight into the staging buffer
+        fill += blob.size();
         plans[k].off = total;
-        total += blobs[k].size();  // multiples of 256
+        total += blob.size();  // multiples of 256
+        host_ms[k] = now_ms() - t0;
     }
-    if (!batch_reserve(d, total + 256 + K * sizeof(sg::BatchItem), K)) return SMARTGPU_ERR_NOMEM;
-    const double t_up = now_ms();
-    // pinned staging -> arena, as many blobs per copy as the staging buffer holds
-    for (uint32_t k = 0; k < K;) {
-        size_t fill = 0;
-        uint32_t j = k;
-        while (j < K && fill + blobs[j].size() <= d->pinned_bytes) {
-            std::memcpy(d->pinned + fill, blobs[j].data(), blobs[j].size());
-            fill += blobs[j].size();
-            ++j;
-        }
-        if (j == k) { set_error("a table blob of %zu bytes exceeds the staging buffer", blobs[k].size()); return SMARTGPU_ERR_NOMEM; }
-        if (hipMemcpyAsync(d->arena + plans[k].off, d->pinned, fill, hipMemcpyHostToDevice, d->stream) != hipSuccess ||
-            hipStreamSynchronize(d->stream) != hipSuccess) {
-            set_error("batch: table upload failed (%s)", hipGetErrorString(hipGetLastError()));
-            return SMARTGPU_ERR_HIP;
-        }
-        k = j;
-    }
-    const double up_ms = (now_ms() - t_up) / K;
+    if (!flush()) { set_error("batch: table upload failed (%s)", hipGetErrorString(hipGetLastError())); return SMARTGPU_ERR_HIP; }
+    const double up_ms = up_total / K;
     if (pre_ms)
         for (uint32_t k = 0; k < K; ++k) pre_ms[k] = host_ms[k] + up_ms;
     return SMARTGPU_OK;
@@ -1316,6 +1307,21 @@ int smartgpu_build_table(int which, const uint8_t* P, uint32_t m, int32_t* out, 
             break;
         }
         case 7: { auto sa = sg::shift_and_masks(P, m); v.assign(sa.begin(), sa.end()); break; }
+        case 9: {  // kmp_runs' tables as the kernel holds them in LDS (bytes; the last 272: Q and thr)
+            const uint32_t w = std::min<uint32_t>(m, sg::kKmpWindow);
+            std::vector<uint8_t> t;
+            sg::kmp_runs_tables(P, w, t);
+            if (w < 63) {  // the blob stores the rows of the states one after the other: spread them out as the kernel does
+                const uint32_t Z = 4 * w + 1;
+                std::vector<uint8_t> lds((Z + 1) * 256 + 272, 0);
+                for (uint32_t st = 0; st <= w; ++st) std::memcpy(&lds[4 * st * 256], &t[st * 256], 256);
+                std::memset(&lds[Z * 256], static_cast<int>(Z), 256);
+                std::memcpy(&lds[(Z + 1) * 256], &t[(w + 1) * 256], 272);
+                t.swap(lds);
+            }
+            v.assign(t.begin(), t.end());
+            break;
+        }
         case 8: v = sg::quick_search_shifts(P, m); break;
         case 13: case 15: case 18: {  // HASHq: 256 shifts + the shift after a candidate
             const uint32_t q = static_cast<uint32_t>(which - 10);

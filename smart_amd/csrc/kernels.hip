@@ -31,6 +31,8 @@
 // kmp_runs1) live in kernels_ab.inc and only in the A/B build (make AB=1, smartgpu_tune).
 #include "kernels.hpp"
 
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <utility>
 
@@ -996,12 +998,16 @@ constexpr int kRunWaves = 16;            // one 1024-thread workgroup per CU sha
 
 // Which group of runs a wave starts with (it then strides by the number of waves in the grid).  A text that
 // gives every wave of the grid a group: the waves of a workgroup take ADJACENT groups — one contiguous stretch
-// of the text per CU (measured: 5-10 % faster than groups a grid apart, whose pages miss the CU's TLB).  A
-// small text: the groups go to different CUs first, one wave per CU working before a second one does.
+// of the text per CU (measured: 5-10 % faster than groups a grid apart, whose pages miss the CU's TLB).  Fewer
+// groups than waves (a small text, or one whose run length was rounded up): workgroup b takes the groups
+// [b*G/B, (b+1)*G/B) — still one contiguous stretch per CU, every CU within one group of the others, and a small
+// text's few groups on different CUs (0.97 GiB, 3974 groups for 4096 waves: KMP 60 % -> with this 69 %).
 __device__ __forceinline__ uint64_t first_group(uint64_t nruns, uint32_t per_group, uint32_t waves, uint32_t wave)
 {
     const uint64_t ngroups = (nruns + per_group - 1) / per_group;
-    return ngroups >= (uint64_t)gridDim.x * waves ? (uint64_t)blockIdx.x * waves + wave : blockIdx.x + (uint64_t)gridDim.x * wave;
+    if (ngroups >= (uint64_t)gridDim.x * waves) return (uint64_t)blockIdx.x * waves + wave;
+    const uint64_t lo = blockIdx.x * ngroups / gridDim.x, hi = (blockIdx.x + 1ull) * ngroups / gridDim.x;
+    return lo + wave < hi ? lo + wave : ngroups;  // ngroups: none (the caller's loop ends at once)
 }
 
 struct RunIo {
@@ -1027,20 +1033,7 @@ __device__ __forceinline__ uint4 run_piece(const RunIo& io, int c)
     return *reinterpret_cast<const uint4*>(io.rd + ((16u * c) ^ io.rswz));
 }
 
-// the 8 loads of one line per run into the named registers n0..n7 (arrays carried across the
-// step loop would go to scratch): the two halves of a line back to back
-#define RUN_FETCH(gbase_, blk_, off_)                                              \
-    do {                                                                           \
-        const uint8_t* p_ = (gbase_) + (off_);                                     \
-        n0 = *reinterpret_cast<const uint4*>(p_ + (blk_)[0]);                      \
-        n4 = *reinterpret_cast<const uint4*>(p_ + (blk_)[0] + 64);                 \
-        n1 = *reinterpret_cast<const uint4*>(p_ + (blk_)[1]);                      \
-        n5 = *reinterpret_cast<const uint4*>(p_ + (blk_)[1] + 64);                 \
-        n2 = *reinterpret_cast<const uint4*>(p_ + (blk_)[2]);                      \
-        n6 = *reinterpret_cast<const uint4*>(p_ + (blk_)[2] + 64);                 \
-        n3 = *reinterpret_cast<const uint4*>(p_ + (blk_)[3]);                      \
-        n7 = *reinterpret_cast<const uint4*>(p_ + (blk_)[3] + 64);                 \
-    } while (0)
+// parking: the four registers of one half into the slab
 #define RUN_PARK(io_, r0_, r1_, r2_, r3_)                                          \
     do {                                                                           \
         *reinterpret_cast<uint4*>((io_).wr) = r0_;                                 \
@@ -1049,18 +1042,19 @@ __device__ __forceinline__ uint4 run_piece(const RunIo& io, int c)
         *reinterpret_cast<uint4*>((io_).wr + 3072) = r3_;                          \
     } while (0)
 
-#define LINE_FETCH(gbase_, blk_, off_)                                             \
+#define LINE_FETCH_R(gbase_, blk_, off_, r0_, r1_, r2_, r3_, r4_, r5_, r6_, r7_)   \
     do {                                                                           \
         const uint8_t* p_ = (gbase_) + (off_);                                     \
-        n0 = ld_stream16(p_ + (blk_)[0]);                                          \
-        n1 = ld_stream16(p_ + (blk_)[1]);                                          \
-        n2 = ld_stream16(p_ + (blk_)[2]);                                          \
-        n3 = ld_stream16(p_ + (blk_)[3]);                                          \
-        n4 = ld_stream16(p_ + (blk_)[4]);                                          \
-        n5 = ld_stream16(p_ + (blk_)[5]);                                          \
-        n6 = ld_stream16(p_ + (blk_)[6]);                                          \
-        n7 = ld_stream16(p_ + (blk_)[7]);                                          \
+        r0_ = ld_stream16(p_ + (blk_)[0]);                                         \
+        r1_ = ld_stream16(p_ + (blk_)[1]);                                         \
+        r2_ = ld_stream16(p_ + (blk_)[2]);                                         \
+        r3_ = ld_stream16(p_ + (blk_)[3]);                                         \
+        r4_ = ld_stream16(p_ + (blk_)[4]);                                         \
+        r5_ = ld_stream16(p_ + (blk_)[5]);                                         \
+        r6_ = ld_stream16(p_ + (blk_)[6]);                                         \
+        r7_ = ld_stream16(p_ + (blk_)[7]);                                         \
     } while (0)
+#define LINE_FETCH(gbase_, blk_, off_) LINE_FETCH_R(gbase_, blk_, off_, n0, n1, n2, n3, n4, n5, n6, n7)
 // ---- the whole-line loader with half-swapped registers (so_runs, kmp_runs) ----------------------
 // LineIo's loads (every 128-byte line requested by ONE non-temporal instruction) with RunIo's parking
 // cost.  Load i fetches the lines of runs 8i .. 8i+7 with lane = 32*half + 4*(run in block) + piece:
@@ -1094,13 +1088,14 @@ __device__ __forceinline__ void swap_halves(uint4& lo, uint4& hi)
 #undef SG_SWAP
 }
 
-#define SWAP_LINE()                \
+#define SWAP_LINE_R(r0_, r1_, r2_, r3_, r4_, r5_, r6_, r7_) \
     do {                           \
-        swap_halves(n0, n1);       \
-        swap_halves(n2, n3);       \
-        swap_halves(n4, n5);       \
-        swap_halves(n6, n7);       \
+        swap_halves(r0_, r1_);     \
+        swap_halves(r2_, r3_);     \
+        swap_halves(r4_, r5_);     \
+        swap_halves(r6_, r7_);     \
     } while (0)
+#define SWAP_LINE() SWAP_LINE_R(n0, n1, n2, n3, n4, n5, n6, n7)
 
 // Shift-Or over per-lane runs, FOUR text bytes per step of the recurrence.
 //
@@ -1323,35 +1318,61 @@ __device__ __forceinline__ void kmp_chunk_fast(const uint4& v, uint32_t& st)
     for (int q = 0; q < 16; ++q) st = kmp_delta(d[q >> 2], st, q & 3);
 }
 
-// Sixteen transitions, four at a time where the whole WAVE is in state 0.  kmp.c:57-60 in state 0 compares the
-// byte with P[0] (kmpNext[0] = -1); four bytes on from state 0 the automaton is in the state of the longest
-// prefix of P that ends the dword: 4 if the dword is P[0..4), else 3 if its last three bytes are P[0..3), ... —
-// four compares and four selects, no lookup, no wait.  On text over a large alphabet nearly every lane is in
-// state 0 nearly always ((127/128)^64 = 60 % of the dword boundaries of a wave on rand128, 78 % on rand256), so
-// z0 — wave-uniform: every lane is in state 0 — holds for most dwords; otherwise the four lookups.  Needs w >= 5
-// (the states 1..4 are plain states with ids 4, 8, 12, 16 in both numberings, and no occurrence can end inside
-// the dword).  nfast counts the dwords that went without lookups (the caller turns this form off where it does
-// not pay: small alphabets, natural language — there z0 practically never holds).
+// Sixteen transitions, four at a time where the whole WAVE is in LOW states.  Four bytes x on from state s the
+// automaton of kmp.c:27-68 is in the state of the longest prefix of P that ends the text there: a prefix of at most
+// four bytes is a suffix of x alone (4 if x is P[0..4), else 3 if its last three bytes are P[0..3), ... — four
+// compares and four selects); a longer one, of L bytes, ends in x = P[L-4..L) and starts with a prefix of L-4 bytes
+// that ended the text before x — s itself or one of its borders.  For a state s WITHOUT a border (kmpNext's chain from
+// s leads straight to 0) that leaves L = s+4: one more compare, against the dword Q[s] = P[s..s+4) — a 256-byte table
+// in LDS next to the transitions, indexed with the state's id 4s as the byte offset.  The host (api.cpp) finds the
+// largest K such that no state 1..K has a border, K+4 < w (no occurrence can end inside the dword: counting stays
+// with the lookups) and the ids up to K+4 are 4s; thr = 4K.  `low` — wave-uniform: every lane's state is at most K
+// — holds for practically every dword on text over a large alphabet and on natural language (a lane beyond K has
+// matched K+1 bytes of P), where z0 of the first version (all lanes in state 0) held for 60 % on rand128 and never on
+// English; on small alphabets the form switches itself off (nfast, the dwords that went without lookups).
+// every lane in a state 0..K = thr/4?  The ids of those states are 4s in both numberings, but an id at most thr need
+// not be one of them: with 63 states or more id(s) = rotl8(s, 2) gives the states from 64 on the ids 1, 5, 9, ... —
+// rotating the id right by two bits (32-bit) sends every id that is not a multiple of 4 beyond any thr.
+__device__ __forceinline__ bool kmp_all_low(uint32_t st, uint32_t thr)
+{
+    return __ballot(__builtin_amdgcn_alignbit(st, st, 2) > (thr >> 2)) == 0;
+}
+
 struct KmpPrefix4 { uint32_t p4, p3, p2, p1; };  // P[0..4) as a dword, P[0..3) << 8, P[0..2) << 16, P[0] << 24
 
-__device__ __forceinline__ void kmp_chunk_skip4(const uint4& v, uint32_t& st, bool& z0, const KmpPrefix4& pf, uint32_t& nfast)
+// the longest prefix of P, of at most four bytes, that ends the dword x (as a state id)
+__device__ __forceinline__ uint32_t kmp_fresh4(uint32_t x, const KmpPrefix4& pf)
+{
+    uint32_t s = (x & 0xFF000000u) == pf.p1 ? 4u : 0u;       // the last byte is P[0]: state 1 (id 4)
+    s = (x & 0xFFFF0000u) == pf.p2 ? 8u : s;                 // the last two are P[0..2): state 2
+    s = (x & 0xFFFFFF00u) == pf.p3 ? 12u : s;                // the last three are P[0..3): state 3
+    return x == pf.p4 ? 16u : s;                             // all four: state 4
+}
+
+// EXT = false: the form for the whole wave in state 0 (thr is 0: registers only); EXT = true: in the states 0..K
+template <bool EXT>
+__device__ __forceinline__ void kmp_chunk_skip4(const uint4& v, uint32_t& st, bool& low, const KmpPrefix4& pf, uint32_t qbase,
+                                                uint32_t thr, uint32_t& nfast)
 {
     const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (z0) {
+        if (low) {
             const uint32_t x = d[k];
-            uint32_t s = (x & 0xFF000000u) == pf.p1 ? 4u : 0u;       // the last byte is P[0]: state 1 (id 4)
-            s = (x & 0xFFFF0000u) == pf.p2 ? 8u : s;                 // the last two are P[0..2): state 2
-            s = (x & 0xFFFFFF00u) == pf.p3 ? 12u : s;                // the last three are P[0..3): state 3
-            s = x == pf.p4 ? 16u : s;                                // all four: state 4
-            st = s;
+            if (EXT) {
+                const uint32_t q = *(const lds_u32_t*)(size_t)(qbase + st);  // P[s..s+4), s = st / 4
+                const uint32_t s = kmp_fresh4(x, pf);
+                st = x == q ? st + 16u : s;                                  // the match went on: state s+4
+            } else {
+                st = kmp_fresh4(x, pf);
+            }
             ++nfast;
+            low = __ballot(st > thr) == 0;
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) st = kmp_delta(d[k], st, q);
+            low = EXT ? kmp_all_low(st, thr) : __ballot(st != 0u) == 0;
         }
-        z0 = __ballot(st != 0u) == 0;
     }
 }
 
@@ -1379,13 +1400,13 @@ __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base,
     }
 }
 
-// RUNIO: the half-line loader of kmp_runs1 (default cache policy) instead of the swap loader.  Measured together with
-// the wave-wide state-0 form (kmp_chunk_skip4), alternating on one box, ms per GiB of rand128:
-//   m <= 32 (tables up to 33 KB): swap loader 0.194-0.199, + state-0 form 0.183-0.187;
-//   m = 64 (full 64 KB table):    half-line 0.206-0.210, swap 0.197-0.199, swap + state-0 form 0.186-0.189;
-//   m = 256, 1024 (PREFIX):       half-line 0.208-0.213, swap 0.206-0.212, either + state-0 form 0.218-0.232.
-// So: patterns up to 254 bytes run <false, false> with the state-0 form, longer ones <true, true> without it.
-template <bool PREFIX, bool RUNIO>  // PREFIX: m > 254 — the automaton of the 254-byte prefix; hits are verified
+// Loader and fast forms, measured alternating on one box, ms per GiB of rand128 (round 2):
+//   m <= 62:  swap loader, a lookup per byte 0.194-0.199; + the state-0 form 0.183-0.187; + the 0..K form where
+//             state 0 does not cover the wave (rand32, English: 0.196 -> 0.188-0.190);
+//   m = 64 .. 254 (full 64 KB table): half-line loader of kmp_runs1 0.206-0.210, swap 0.197-0.199, + forms 0.183-0.19;
+//   m > 254 (PREFIX): half-line 0.207-0.213, swap 0.206-0.212, swap + the 0..K form 0.196-0.199 (the state-0 form
+//             on its own made it slower: 0.218-0.232).
+template <bool PREFIX>  // PREFIX: m > 254 — the automaton of the 254-byte prefix; hits are verified
 __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
                                                            uint32_t dfa_off, const BatchItem* __restrict__ batch)
 {
@@ -1404,11 +1425,24 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         pf.p2 = p << 16;
         pf.p1 = p << 24;
     }
-    const RunIo io = RUNIO ? run_io(smem + table_bytes + wave * kLineSlab, lane, run_len) : swap_io(smem + table_bytes + wave * kLineSlab, lane, run_len);
+    const uint32_t qbase = table_bytes;  // Q[s] = P[s..s+4) for the states kmp_chunk_skip4 covers (256 bytes)
+    const uint32_t stored = (w < 63 ? w + 1 : 256u) * 256u;  // the blob's rows (tables.cpp kmp_runs_tables)
+    const uint32_t thr = *reinterpret_cast<const uint32_t*>(a.blob + dfa_off + stored + 256);
+    uint8_t* const slabs = smem + table_bytes + kKmpQBytes;
+    const RunIo io = swap_io(slabs + wave * kLineSlab, lane, run_len);
     {
         const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
         uint4* t = reinterpret_cast<uint4*>(smem);
-        for (uint32_t i = threadIdx.x; i < table_bytes / 16; i += kRunWaves * 64) t[i] = g[i];
+        if (w < 63) {
+            // the blob holds the rows of the states 0..w one after the other: row s goes to row 4s (the rows between
+            // are never addressed), row Z is filled here, Q follows the table
+            for (uint32_t i = threadIdx.x; i < (w + 1) * 16; i += kRunWaves * 64) t[(i >> 4) * 64 + (i & 15u)] = g[i];
+            const uint32_t z4 = Z * 0x01010101u;
+            if (threadIdx.x < 16) t[Z * 16 + threadIdx.x] = make_uint4(z4, z4, z4, z4);
+            else if (threadIdx.x < 32) t[table_bytes / 16 + threadIdx.x - 16] = g[stored / 16 + threadIdx.x - 16];
+        } else {
+            for (uint32_t i = threadIdx.x; i < (table_bytes + 256) / 16; i += kRunWaves * 64) t[i] = g[i];
+        }
     }
     // the perm result IS the LDS address: the table sits at LDS offset 0 (no static LDS in
     // this kernel, so the dynamic segment starts there); a poisoned count if that ever changes
@@ -1426,19 +1460,32 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
         uint32_t blk[8];  // a block that lies entirely past the last run re-reads block 0 (loaded, never consumed)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) blk[i] = g * 64 + (RUNIO ? 16 : 8) * i < nruns ? (RUNIO ? 16u : 8u) * i * run_len : 0u;
+        for (int i = 0; i < 8; ++i) blk[i] = g * 64 + 8 * i < nruns ? 8u * i * run_len : 0u;
         const uint64_t my = g * 64 + lane;
         const uint64_t seg = (run_first + my) * run_len;
         const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
         const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
         const bool owner = my < nruns && sa < sb;
+        // A lane without a run (the last group of a text is rarely full) walks what its slab holds — a re-read block
+        // of the group, or the text's back pad — over the full length, and its hits are dropped at the end of the
+        // group: with j0 = jend = 0 it would make every half of its wave run both the straight path (its neighbours)
+        // and the careful one, and that one wave ends the kernel 7-10 % late (measured: 2^30 bytes against 2^30 - 26
+        // runs).  Not for PREFIX: its hits read the text at the run's offset.
+        const bool ghost = !PREFIX && !owner;
         const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
-        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;
+        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : ghost ? run_len + w - 1 : 0u;
+        const uint32_t hits_before = hits;
 
         uint4 n0, n1, n2, n3, n4, n5, n6, n7;
-        if (RUNIO) RUN_FETCH(gbase, blk, 0u); else LINE_FETCH(gbase, blk, 0u);
+        LINE_FETCH(gbase, blk, 0u);
         uint32_t st = 0;
-        bool skip4 = !PREFIX && w >= 5;  // wave-uniform: the wave-wide state-0 form pays (kmp_chunk_skip4); probed again every 8 lines
+        // wave-uniform: which form walks the whole halves — 1: four bytes at a time while every lane is in state 0
+        // (registers only; most dwords on a large alphabet), 2: while every lane is in a state 0..K (one Q lookup per
+        // dword; natural language, medium alphabets — not worth trying with K < 4), 0: a lookup per byte.  A half in
+        // which a form covered fewer than 6 of the 16 dwords hands over to the next one; tried again from the top every
+        // 8 lines.  The prefix automaton starts with form 2 (measured, above).
+        const uint32_t mode0 = w < 5 ? 0u : !PREFIX ? 1u : thr >= 16u ? 2u : 0u;
+        uint32_t mode = mode0;
         bool dense = false;   // wave-uniform: many lanes saw an occurrence end in the last whole half
         bool parked = false;  // PREFIX: first unverified prefix hit of this step
         const uint8_t* parked_at = a.text;
@@ -1475,15 +1522,24 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
                 bool seen = false;
                 if (!dense) {
                     uint32_t at[4];  // state before each 16-byte chunk
-                    if (skip4) {
-                        bool z0 = __ballot(st != 0u) == 0;
+                    if (mode == 1) {
+                        bool low = __ballot(st != 0u) == 0;
                         uint32_t nfast = 0;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             at[q] = st;
-                            kmp_chunk_skip4(run_piece(io, q), st, z0, pf, nfast);
+                            kmp_chunk_skip4<false>(run_piece(io, q), st, low, pf, qbase, 0u, nfast);
                         }
-                        skip4 = nfast >= 4;  // of 16 dwords: below that the compares cost more than the lookups they save
+                        if (nfast < 6) mode = thr >= 16u ? 2u : 0u;
+                    } else if (mode == 2) {
+                        bool low = kmp_all_low(st, thr);
+                        uint32_t nfast = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            at[q] = st;
+                            kmp_chunk_skip4<true>(run_piece(io, q), st, low, pf, qbase, thr, nfast);
+                        }
+                        if (nfast < 6) mode = 0u;
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -1522,15 +1578,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
             }
         };
         for (uint32_t k = 0; k < nlines; ++k) {
-            if ((k & 7u) == 7u) skip4 = !PREFIX && w >= 5;
-            if (RUNIO) {
-                RUN_PARK(io, n0, n1, n2, n3);
-                half(k * kRunLine);
-                RUN_PARK(io, n4, n5, n6, n7);
-                if (k + 1 < nlines) RUN_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
-                half(k * kRunLine + 64u);
-                continue;
-            }
+            if ((k & 7u) == 7u) mode = mode0;
             SWAP_LINE();
             RUN_PARK(io, n0, n2, n4, n6);
             half(k * kRunLine);
@@ -1538,6 +1586,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
             if (k + 1 < nlines) LINE_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
             half(k * kRunLine + 64u);
         }
+        if (ghost) hits = hits_before;
     }
     flush_hits(hits, a.count, smem);
 }
@@ -2029,13 +2078,32 @@ static uint64_t balanced_run_len(uint64_t s_begin, uint64_t s_end, uint64_t per_
     const uint64_t span = s_end - s_begin;
     const uint64_t slots = per_group * nwaves;  // runs per round of all waves
     const uint64_t k = (span + slots * lmax - 1) / (slots * lmax);
-    uint64_t L = ((span + slots * k - 1) / (slots * k) + 63) & ~63ull;
+    // Runs are cut on absolute offsets and fetched 128 bytes at a time: a length that is not a multiple of 128
+    // puts every second run's fetches across two memory lines (measured: 0.97 GiB, runs of 4032 bytes, 57 % where
+    // 0.9 and 1.0 GiB — 3712 and 4096 — reach 79-82 %).
+    uint64_t L = ((span + slots * k - 1) / (slots * k) + 127) & ~127ull;
     // A text too small to give every wave a group of lmin-byte runs (SMART's stock 1 MiB texts: 8 groups of
     // 2 KiB runs = 8 waves on the whole chip, 60-70 us per search): shorter runs, down to lfloor — the
     // re-scan of w-1 bytes per run costs less than the idle CUs.
-    if (L < lmin) return L > lfloor ? L : (lfloor + 63) & ~63ull;
-    while (tiles_for(s_begin, s_end, L).count > slots * k) L += 64;
+    if (L < lmin) return L > lfloor ? L : (lfloor + 127) & ~127ull;
+    while (tiles_for(s_begin, s_end, L).count > slots * k) L += 128;
     return L;
+}
+
+// Workgroups per pattern of the runs kernels (one 1024-thread workgroup per CU, first_group hands every workgroup a
+// contiguous share of the groups of 64 runs).  One pattern: as many workgroups as there are groups, up to one per CU —
+// a small text is spread over the chip, one wave per CU.  A pattern set in one grid (gridDim.y patterns, SMART's -pset
+// loop on its 1 MiB texts): every workgroup copies its pattern's table (up to 64 KB) before it starts, so with enough
+// patterns to fill the chip the groups are packed 16 to a workgroup — 500 patterns x 128 groups of 128-byte runs:
+// 4000 workgroups with all waves busy instead of 64000 with one (KMP 4.3 -> 0.6 us per pattern, measured).
+static uint64_t runs_grid(uint64_t nruns, int num_cus)
+{
+    const uint64_t groups = (nruns + 63) / 64;
+    const uint64_t spread = groups < (uint64_t)num_cus ? groups : (uint64_t)num_cus;
+    const uint64_t packed = (groups + kRunWaves - 1) / kRunWaves;
+    uint64_t want = (2ull * num_cus + g_batch.count - 1) / g_batch.count;  // enough workgroups for two rounds of the chip
+    if (want < packed) want = packed;
+    return want < spread ? want : spread;
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel), not per launch
@@ -2061,8 +2129,7 @@ static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus,
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
     const size_t lds = 65536 + kRunWaves * (size_t)kLineSlab;
-    uint64_t grid = ((uint64_t)tr.count + 63) / 64;  // groups of 64 runs: spread over the CUs first (so_runs: group = block + grid * wave)
-    if (grid > (uint64_t)num_cus) grid = num_cus;
+    const uint64_t grid = runs_grid(tr.count, num_cus);
 #ifdef SMARTGPU_AB
 #define SG_SO_RUNS1(L_, A_)                                                                               \
     do {                                                                                                 \
@@ -2098,7 +2165,7 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
 #ifdef SMARTGPU_AB
     const bool links = g_tune[3] == 2;  // failure links
     const bool v1 = g_tune[3] == 3;     // the previous kernel (running maximum, half-line loader): its table follows
-    const uint32_t dfa1_off = dfa_off + rows * 256;
+    const uint32_t dfa1_off = dfa_off + (w < 63 ? w + 1 : 256u) * 256 + kKmpQBytes;
     if (links || v1) w = (links || m <= kKmpDfaMaxM) ? m : kKmpDfaMaxM;
     if (links) {
         const uint64_t span = a.s_end - a.s_begin;
@@ -2123,7 +2190,7 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     const size_t table = (size_t)rows * 256;
 #endif
     // one 1024-thread workgroup per CU shares the table (<= 64 KB) next to 16 x 4 KB of slabs
-    const size_t lds = table + kRunWaves * (size_t)kLineSlab;
+    const size_t lds = table + kKmpQBytes + kRunWaves * (size_t)kLineSlab;
     // runs of 2-4 KiB: at least 8x the w-1 bytes a run re-scans, at most 8 KiB (the loader's
     // over-read past the last run stays inside the text's back pad)
     uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
@@ -2132,8 +2199,8 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin, lfloor);
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
-    uint64_t grid = ((uint64_t)tr.count + 63) / 64;  // groups of 64 runs: spread over the CUs first
-    if (grid > (uint64_t)num_cus) grid = num_cus;
+    const uint64_t grid = runs_grid(tr.count, num_cus);
+    if (getenv("SMARTGPU_DEBUG")) fprintf(stderr, "kmp_runs: span [%llu, %llu) L %llu runs %llu first %llu grid %llu\n", (unsigned long long)a.s_begin, (unsigned long long)a.s_end, (unsigned long long)L, (unsigned long long)tr.count, (unsigned long long)tr.first, (unsigned long long)grid);
 #define SG_KMP_RUNS(K_, OFF_)                                                                            \
     do {                                                                                                 \
         if (lds > 64 * 1024) allow_lds(reinterpret_cast<const void*>(K_), lds);                          \
@@ -2146,10 +2213,8 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     } else
 #endif
     {
-        // the prefix automaton of patterns beyond 254 bytes: behind the half-line loader, without the wave-wide
-        // state-0 form (measured, see kmp_runs)
-        if (m > kKmpWindow) SG_KMP_RUNS((kmp_runs<true, true>), dfa_off);
-        else SG_KMP_RUNS((kmp_runs<false, false>), dfa_off);
+        if (m > kKmpWindow) SG_KMP_RUNS(kmp_runs<true>, dfa_off);
+        else SG_KMP_RUNS(kmp_runs<false>, dfa_off);
     }
 #undef SG_KMP_RUNS
     return hipGetLastError();

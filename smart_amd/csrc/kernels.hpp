@@ -21,6 +21,7 @@ constexpr int kResultSlots = 4096;
 constexpr uint32_t kSoWindow = 29;     // SO/SA: bytes of the pattern so_runs keeps in its 32-bit state (four steps of the
                                        // recurrence at once need three bits of headroom); longer patterns: prefix + verification
 constexpr uint32_t kKmpWindow = 254;   // KMP (kmp_runs): states 0..w plus the absorbing accept row are u8 ids: w = min(m, 254)
+constexpr uint32_t kKmpQBytes = 272;   // kmp_runs: after the transitions, Q[s] = P[s..s+4) for 64 states (LDS), thr = 4K, 12 bytes of padding
 constexpr uint32_t kKmpDfaMaxM = 255;  // KMP: the automaton's states are u8, so its (w+1)*256-byte transition
                                        // table (<= 64 KB of LDS) recognises w = min(m, 255) bytes; longer
                                        // patterns: the automaton of the 255-byte prefix + verification

@@ -2,6 +2,7 @@
 #include "tables.hpp"
 
 #include <algorithm>
+#include <cstring>
 
 namespace sg {
 
@@ -92,6 +93,70 @@ std::vector<uint8_t> kmp_dfa(const uint8_t* P, uint32_t m)
         if (s < m) row[P[s]] = static_cast<uint8_t>(s + 1);
     }
     return dfa;
+}
+
+uint32_t kmp_runs_table_bytes(uint32_t w) { return (w < 63 ? w + 1 : 256u) * 256u; }
+
+void kmp_runs_tables(const uint8_t* P, uint32_t w, std::vector<uint8_t>& out)
+{
+    // ids: fewer than 63 states: id(s) = 4s, Z = 4w + 1, the table ends there.  Otherwise id(s) = rotl8(s, 2) — the
+    // low states a lane is usually in then differ in the bits that select the LDS bank —, id(w) = 254, Z = 255;
+    // rotl8 maps only s = 191 to 254 and only s = 255 to 255, so state 191 (if there is one besides w) takes the
+    // slot w gave up.  Z = id(w) + 1 is the largest id (the kernel's min(next, id(w)) turns Z back into w).
+    const bool small = w < 63;
+    const uint32_t idw = small ? 4 * w : 254u, Z = idw + 1;
+    uint8_t id[256];
+    for (uint32_t st = 0; st <= w; ++st) id[st] = static_cast<uint8_t>(small ? 4 * st : ((st << 2) | (st >> 6)) & 255u);
+    if (!small && w > 191) id[191] = id[w];
+    id[w] = static_cast<uint8_t>(idw);
+    // bd[s] = longest proper border of P[0..s) (kmp.c:27-41 without the kmpNext[i] = kmpNext[j] shortcut)
+    uint8_t bd[256];
+    bd[0] = bd[1] = 0;
+    for (uint32_t s = 2, k = 0; s <= w; ++s) {
+        while (k && P[s - 1] != P[k]) k = bd[k];
+        if (P[s - 1] == P[k]) ++k;
+        bd[s] = static_cast<uint8_t>(k);
+    }
+    // Stored rows: with fewer than 63 states row s of the blob is the table's row 4s (the kernel spreads them out
+    // in LDS and fills row Z itself: a quarter of the bytes to build, stage, upload and fetch); otherwise all 256.
+    const size_t base = out.size();
+    out.resize(base + kmp_runs_table_bytes(w) + 272, 0);
+    uint8_t* const tab = out.data() + base;
+    auto into = [&](uint32_t st) { return static_cast<uint8_t>(st == w ? Z : id[st]); };  // a transition INTO st
+    auto row = [&](uint32_t st) { return tab + (small ? st : id[st]) * 256u; };
+    // state 0 (row 0, swizzle 0): everything to 0 except P[0]
+    tab[P[0]] = into(1);
+    for (uint32_t s = 1; s <= w; ++s) {
+        // delta(s, c) = s+1 on a match, otherwise delta(border(s), c): the border's finished row, re-swizzled —
+        // entry c sits at c ^ id, so dst[j] = src[j ^ id(s) ^ id(border)]
+        const uint32_t r = id[s], rb = id[bd[s]], d = r ^ rb;
+        const uint8_t* src = row(bd[s]);
+        uint8_t* dst = row(s);
+        if ((d & 3) == 0) {
+            for (uint32_t j = 0; j < 256; j += 4) std::memcpy(dst + j, src + (j ^ d), 4);
+        } else {  // the ids of 63+ states are not multiples of 4: the bytes of every dword change places too
+            for (uint32_t j = 0; j < 256; j += 4) {
+                uint32_t x;
+                std::memcpy(&x, src + ((j ^ d) & ~3u), 4);
+                if (d & 1) x = ((x & 0x00FF00FFu) << 8) | ((x >> 8) & 0x00FF00FFu);
+                if (d & 2) x = (x << 16) | (x >> 16);
+                std::memcpy(dst + j, &x, 4);
+            }
+        }
+        if (s < w) dst[P[s] ^ r] = into(s + 1);
+    }
+    if (!small) std::memset(tab + Z * 256, static_cast<int>(Z), 256);
+    // the four-bytes-at-a-time forms (kmp_chunk_skip4): K + 4 < w (no occurrence ends in the dword) and K + 4 <= 62
+    // (the ids are 4s up there in both numberings)
+    uint8_t* const q = tab + kmp_runs_table_bytes(w);
+    if (w >= 5) {
+        const uint32_t cap = std::min<uint32_t>(w - 5, 58);
+        uint32_t K = 0;
+        while (K < cap && bd[K + 1] == 0) ++K;
+        for (uint32_t s = 0; s <= K; ++s) std::memcpy(q + 4 * s, P + s, 4);  // the dword as the text holds it
+        const uint32_t thr = 4 * K;
+        std::memcpy(q + 256, &thr, 4);
+    }
 }
 
 std::vector<uint8_t> kmp_dfa_compressed(const uint8_t* P, uint32_t m, uint32_t* k1)

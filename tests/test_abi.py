@@ -146,6 +146,11 @@ int main() {
                         int32_t after = 0;
                         sink += sg::qgram_hash_shifts(P.data(), m, q, &after)[P[m - 1]] + after;
                     }
+                {
+                    std::vector<uint8_t> t(m % 7, 0);  // appended after what the blob already holds
+                    sg::kmp_runs_tables(P.data(), m < 254 ? m : 254, t);
+                    sink += t.back() + t.size();
+                }
                 if (m <= 255) {
                     uint32_t k1 = 0;
                     sink += sg::kmp_dfa(P.data(), m)[m * 256u + P[0]];
@@ -161,6 +166,53 @@ int main() {
                            "-I", os.path.join(ROOT, "smart_amd", "csrc"), str(drv), src, "-o", str(exe)])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
+
+def test_kmp_runs_tables_are_the_automaton_renumbered(oracle):
+    """kmp_runs' tables (tables.cpp kmp_runs_tables, built row by row in place) against the layout DESIGN.md §4
+    states, reconstructed here from the plain transition table: row id(s) XOR-swizzled by its id, transitions into
+    the accept state lead to the absorbing row Z; Q[s] = P[s..s+4) for the borderless states 0..K, thr = 4K."""
+    rng = np.random.default_rng(5)
+    cases = [oracle.gen_text(77 + i, sigma, 0, m) for i, (sigma, m) in enumerate(
+        [(2, 5), (2, 9), (2, 40), (2, 62), (2, 63), (2, 64), (2, 200), (2, 254), (4, 17), (4, 100), (4, 254), (128, 1), (128, 2),
+         (128, 4), (128, 5), (128, 6), (128, 32), (128, 62), (128, 63), (128, 191), (128, 192), (128, 193), (128, 254), (128, 300)])]
+    cases += [np.frombuffer(b"abcabcabcabd", np.uint8), np.frombuffer(b"aaaaaaaaab", np.uint8), np.frombuffer(b"abcdeabcdeabcdf", np.uint8)]
+    cases += [np.tile(np.frombuffer(b"ab", np.uint8), 120), np.concatenate([rng.integers(0, 256, 250, dtype=np.uint8), [7, 7, 7, 7]]).astype(np.uint8)]
+    for P in cases:
+        w = min(len(P), 254)
+        Pw = P[:w]
+        dfa = smart_amd.build_table("kmp_dfa", Pw).reshape(w + 1, 256)
+        got = smart_amd.build_table("kmp_runs", P).astype(np.uint8)
+        small = w < 63
+        idw = 4 * w if small else 254
+        Z = idw + 1
+        rot = lambda s: ((s << 2) | (s >> 6)) & 255  # noqa: E731
+        ident = lambda s: idw if s == w else 4 * s if small else rot(w) if s == 191 else rot(s)  # noqa: E731
+        assert len(got) == (Z + 1) * 256 + 272, (len(P), len(got))
+        want = np.zeros((Z + 1, 256), np.uint8)
+        ids = [ident(s) for s in range(w + 1)]
+        assert len(set(ids)) == w + 1 and Z not in ids
+        for s in range(w + 1):
+            r = ids[s]
+            for c in range(256):
+                nx = int(dfa[s, c])
+                want[r, c ^ r] = Z if nx == w else ids[nx]
+        want[Z, :] = Z
+        assert np.array_equal(got[:(Z + 1) * 256].reshape(Z + 1, 256), want), len(P)
+        q = got[(Z + 1) * 256:].view(np.uint32)
+        border = [0, 0]
+        for s in range(2, w + 1):  # longest proper border of P[0..s)
+            k = border[s - 1]
+            while k and Pw[s - 1] != Pw[k]:
+                k = border[k]
+            border.append(k + 1 if Pw[s - 1] == Pw[k] else 0)
+        K = 0
+        if w >= 5:
+            while K < min(w - 5, 58) and border[K + 1] == 0:
+                K += 1
+            for s in range(K + 1):
+                assert q[s] == int.from_bytes(bytes(Pw[s:s + 4]), "little"), (len(P), s)
+        assert q[64] == 4 * K and not q[65:].any() and not q[K + 1:64].any()
 
 
 def test_kernel_choice_follows_the_pattern(oracle):
@@ -193,14 +245,16 @@ def test_kernel_choice_follows_the_pattern(oracle):
             want = {"kmp": "kmp_runs", "kr": "hor_scan_bp"}.get(a, "so_runs")
             assert kf(a, two[:m]) == want, (a, m)
     assert kf("hor", two[:12]) == "so_runs" and kf("epsm", two[:12]) == "packed_scan"
-    # the serial automata never move
-    for P in (rnd[:32], eng[:32], four[:32]):
+    # the serial automata never move — KMP from 5 bytes on (below that kmp_runs has no four-bytes-at-a-time form)
+    for P in (rnd[:32], eng[:32], four[:32], rnd[:5], two[:5]):
         assert kf("kmp", P) == "kmp_runs" and kf("so", P) == "so_runs" and kf("sa", P) == "so_runs"
+    assert kf("kmp", rnd[:4]) == "so_runs" and kf("kmp", eng[:2]) == "so_runs" and kf("kmp", rnd[:1]) == "so_runs"
     assert kf("epsm", rnd[:32]) == "packed_scan" and kf("epsm", eng[:32]) == "packed_scan"  # EPSM is the packed matcher
     # tune(0,1): every algorithm on its own kernel
     engine.tune(0, 1)
     try:
         assert kf("bm", eng[200:264]) == "bm_scan" and kf("hor", two[:64]) == "hor_scan" and kf("kr", rnd[:8]) == "hor_scan_bp"
+        assert kf("kmp", rnd[:4]) == "kmp_runs"
     finally:
         engine.tune(0, 0)
     with pytest.raises(smart_amd.SmartGpuError):
