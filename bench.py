@@ -392,11 +392,14 @@ def main():
 
 
 def run_sweep(text128, device):
-    """Cells of BASELINE config 2 (six algorithms x m in {4,8,32,256}, 1 GiB rand128) and config 3
-    (SO and BNDM x sigma in {2,4} x m in {2,4,8,16,32,64}, 1 GiB), the harness loop of
-    src/smart.c:290-345 reduced to what it times: per cell 3 patterns x 4 launches between two HIP
-    events on the launch stream.  Every cell names the kernel its plans launched; a cell whose plans
-    were rerouted (api.cpp build_blob) is measured again on the algorithm's own kernel."""
+    """Cells of BASELINE config 2 (six algorithms x m in {4,8,32,256}, 1 GiB rand128), config 3
+    (SO and BNDM x sigma in {2,4} x m in {2,4,8,16,32,64}, 1 GiB), config 4's corpus (the English
+    unit bible.txt||world192.txt tiled to 1 GiB here, six algorithms x the lengths of sets.h:25) and
+    config 5's alphabets (sigma in {2,32,256} x HOR/BM/KMP/SO/EPSM x sets.h:25, one 1 GiB shard):
+    the harness loop of src/smart.c:290-345 reduced to what it times: per cell 3 patterns x 4
+    launches between two HIP events on the launch stream.  Every cell names the kernel its plans
+    launched; a cell whose plans were rerouted (api.cpp build_blob) is measured again on the
+    algorithm's own kernel."""
     import numpy as np
     import smart_amd
     from smart_amd import Plan, Text, engine
@@ -406,7 +409,7 @@ def run_sweep(text128, device):
     cells = []
     ref_counts = {}
 
-    def time_cell(text, sigma, algo, m, pats, own):
+    def time_cell(config, text, sigma, algo, m, pats, own):
         if own:
             engine.tune(0, 1)
         try:
@@ -435,7 +438,7 @@ def run_sweep(text128, device):
         for pl in plans:
             pl.free()
         kernel = kernels.most_common(1)[0][0]
-        cell = {"algo": algo, "m": m, "sigma": sigma, "kernel": kernel, "ms": round(ms, 4),
+        cell = {"config": config, "algo": algo, "m": m, "sigma": sigma, "kernel": kernel, "ms": round(ms, 4),
                 "frac": round(n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "count_ok": bool(ok)}
         if len(kernels) > 1:
             cell["kernels"] = dict(kernels)
@@ -443,33 +446,55 @@ def run_sweep(text128, device):
             cell["own_kernel"] = True  # smartgpu_tune(0,1): the algorithm's own kernel, not the plan's choice
         return cell
 
-    def cells_for(text, sigma, algos, ms):
+    def cells_for(config, text, sigma, algos, ms, unit=None):
         for m in ms:
-            pats = [text.pattern(splitmix64(PATTERN_SALT + 4096 * j + m) % (n - m), m) for j in range(J)]
+            if unit is None:
+                pats = [text.pattern(splitmix64(PATTERN_SALT + 4096 * j + m) % (n - m), m) for j in range(J)]
+            else:  # config 4: patterns from the first copy of the unit
+                pats = [unit[k:k + m] for k in (splitmix64(PATTERN_SALT + 4096 * j + m) % (len(unit) - m) for j in range(J))]
             for algo in algos:
-                c = time_cell(text, sigma, algo, m, pats, own=False)
+                if m < smart_amd.MIN_M.get(algo, 1):
+                    continue
+                c = time_cell(config, text, sigma, algo, m, pats, own=False)
                 cells.append(c)
                 if c["kernel"] != OWN_KERNEL[algo] or "kernels" in c:
-                    cells.append(time_cell(text, sigma, algo, m, pats, own=True))
+                    cells.append(time_cell(config, text, sigma, algo, m, pats, own=True))
 
     own128 = text128 is None
     if own128:
         text128 = Text.generate(SEED, 128, n, device=device)
-    cells_for(text128, 128, ("hor", "bm", "kmp", "so", "bndm", "epsm"), (4, 8, 32, 256))
+    SETS_H_25 = (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096)  # src/sets.h:25
+    cells_for(2, text128, 128, ("hor", "bm", "kmp", "so", "bndm", "epsm"), (4, 8, 32, 256))
     if own128:
         text128.free()
     for sigma in (4, 2):
         t = Text.generate(SEED, sigma, n, device=device)
-        cells_for(t, sigma, ("so", "bndm"), (2, 4, 8, 16, 32, 64))
+        cells_for(3, t, sigma, ("so", "bndm"), (2, 4, 8, 16, 32, 64))
+        if sigma == 2:
+            cells_for(5, t, sigma, ("hor", "bm", "kmp", "so", "epsm"), SETS_H_25)
         t.free()
+    for sigma in (32, 256):
+        t = Text.generate(SEED, sigma, n, device=device)
+        cells_for(5, t, sigma, ("hor", "bm", "kmp", "so", "epsm"), SETS_H_25)
+        t.free()
+    from smart_amd import corpus
+    unit = corpus.english_unit()
+    t = Text.upload_tiled(unit, n, device=device)
+    cells_for(4, t, "english", ("hor", "bm", "kmp", "so", "bndm", "epsm"), SETS_H_25, unit=unit)
+    t.free()
     bad = [c for c in cells if not c["count_ok"]]
     if bad:
         raise SystemExit("SWEEP COUNT MISMATCH: %s" % bad)
-    north = [c["frac"] for c in cells if c["sigma"] == 128 and not c.get("own_kernel")]
+    north = [c["frac"] for c in cells if c["config"] == 2 and not c.get("own_kernel")]
+    plan = lambda k: [c["frac"] for c in cells if c["config"] == k and not c.get("own_kernel")]  # noqa: E731
     return {"cells": cells,
             "min_frac": {"rand128_m4to256_plan_choice": min(north),
+                         "config3_plan_choice": min(plan(3)), "config4_english_plan_choice": min(plan(4)),
+                         "config5_plan_choice": min(plan(5)),
                          "all_cells": min(c["frac"] for c in cells)},
-            "note": "1 GiB per cell; ms = HIP events over %d launches (%d patterns x %d); frac = 2^30 B / ms / 8 TB/s; "
+            "note": "config = BASELINE.json configuration the cell belongs to (4: the English unit tiled to 1 GiB, 5: one 1 GiB "
+                    "shard per alphabet; their 4 GiB sizes: profiles/ sweeps, tests/test_configs_gpu.py); "
+                    "1 GiB per cell; ms = HIP events over %d launches (%d patterns x %d); frac = 2^30 B / ms / 8 TB/s; "
                     "own_kernel = measured again with smartgpu_tune(0,1) because the plan rerouted the pattern" % (J * REPS, J, REPS)}
 
 

@@ -271,10 +271,10 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
             append(tab.data(), tab.size() * 2);
             *halo = m - 1;  // forward halo: the automaton re-scans m-1 bytes
             blob.resize((blob.size() + 15) & ~size_t(15), 0);  // the transition table is 16-byte aligned
-            // kmp_runs: the automaton over w = min(m, 254) bytes with an ABSORBING accept row Z (every transition into
+            // kmp_runs: the automaton over w = kmp_window(m) bytes (the pattern, or its 62-byte prefix beyond 254) with an ABSORBING accept row Z (every transition into
             // the accept state w leads to Z, Z leads to Z; row id(w) holds the real delta(w, .)), and the table of the
             // four-bytes-at-a-time forms (tables.cpp)
-            sg::kmp_runs_tables(P, std::min<uint32_t>(m, sg::kKmpWindow), blob);
+            sg::kmp_runs_tables(P, sg::kmp_window(m), blob);
 #ifdef SMARTGPU_AB
             {   // kmp_runs1 (A/B build): the automaton of P[0..w), w = min(m, 255); state s is row id(s) = rotl8(s, 2),
                 // the accept state row 255 — or row 4w while the ids 4s do not wrap (w < 64) —, the largest id (its
@@ -1308,7 +1308,7 @@ int smartgpu_build_table(int which, const uint8_t* P, uint32_t m, int32_t* out, 
         }
         case 7: { auto sa = sg::shift_and_masks(P, m); v.assign(sa.begin(), sa.end()); break; }
         case 9: {  // kmp_runs' tables as the kernel holds them in LDS (bytes; the last 272: Q and thr)
-            const uint32_t w = std::min<uint32_t>(m, sg::kKmpWindow);
+            const uint32_t w = sg::kmp_window(m);
             std::vector<uint8_t> t;
             sg::kmp_runs_tables(P, w, t);
             if (w < 63) {  // the blob stores the rows of the states one after the other: spread them out as the kernel does

@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
 // (bank swizzle), ds_read_u8.
 // State ids (api.cpp build_blob): fewer than 63 states: id(s) = 4s, the table ends with row Z = 4w+1;
 // otherwise id(s) = rotl8(s, 2) with id(w) = 254, Z = 255 (the one state that would sit on 254, s = 191,
-// takes the slot w left free).  w = min(m, 254); longer patterns: the 254-byte prefix's automaton, a
+// takes the slot w left free).  w = m up to 254 bytes; longer patterns: the 62-byte prefix's automaton (kKmpPrefix), a
 // prefix hit is parked and verified (wave_verify) — what so.c does with its 32-byte prefix.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t sad_now(uint32_t a, uint32_t b, uint32_t c)
@@ -1406,7 +1406,7 @@ __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base,
 //   m = 64 .. 254 (full 64 KB table): half-line loader of kmp_runs1 0.206-0.210, swap 0.197-0.199, + forms 0.183-0.19;
 //   m > 254 (PREFIX): half-line 0.207-0.213, swap 0.206-0.212, swap + the 0..K form 0.196-0.199 (the state-0 form
 //             on its own made it slower: 0.218-0.232).
-template <bool PREFIX>  // PREFIX: m > 254 — the automaton of the 254-byte prefix; hits are verified
+template <bool PREFIX>  // PREFIX: m > 254 — the automaton of the 62-byte prefix; hits are verified
 __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
                                                            uint32_t dfa_off, const BatchItem* __restrict__ batch)
 {
@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t w = PREFIX ? kKmpWindow : m;  // length the automaton recognises
+    const uint32_t w = PREFIX ? kKmpPrefix : m;  // length the automaton recognises
     const uint32_t idw = w < 63 ? 4 * w : 254u, Z = idw + 1;
     const uint32_t table_bytes = (Z + 1) * 256;
     KmpPrefix4 pf;
@@ -1466,15 +1466,8 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         const uint64_t sa = seg > a.s_begin ? seg : a.s_begin;
         const uint64_t sb = seg + run_len < a.s_end ? seg + run_len : a.s_end;
         const bool owner = my < nruns && sa < sb;
-        // A lane without a run (the last group of a text is rarely full) walks what its slab holds — a re-read block
-        // of the group, or the text's back pad — over the full length, and its hits are dropped at the end of the
-        // group: with j0 = jend = 0 it would make every half of its wave run both the straight path (its neighbours)
-        // and the careful one, and that one wave ends the kernel 7-10 % late (measured: 2^30 bytes against 2^30 - 26
-        // runs).  Not for PREFIX: its hits read the text at the run's offset.
-        const bool ghost = !PREFIX && !owner;
         const uint32_t j0 = owner ? (uint32_t)(sa - seg) : 0u;
-        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : ghost ? run_len + w - 1 : 0u;
-        const uint32_t hits_before = hits;
+        const uint32_t jend = owner ? (uint32_t)(sb - seg) + w - 1 : 0u;  // bytes [j0, jend) of the run can end an occurrence
 
         uint4 n0, n1, n2, n3, n4, n5, n6, n7;
         LINE_FETCH(gbase, blk, 0u);
@@ -1491,18 +1484,23 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         const uint8_t* parked_at = a.text;
         auto half = [&](const uint32_t jb) {
             // one 16-byte chunk, counting; returns whether an occurrence ended in it
+            // A chunk outside [j0, jend) — the text's last run ends early, the lanes of the last group may have no run
+            // at all — must cost nothing, not even its slab read: such a lane makes its wave run this path next to the
+            // straight one in every half, and with the read in front of the test that one wave ended the kernel 7-10 %
+            // late (measured: 2^30 bytes against 2^30 - 26 runs; m = 4096, whose last run has ONE start, against 1024).
             auto careful = [&](uint32_t q, bool whole) -> bool {
-                const uint4 v = *reinterpret_cast<const uint4*>(io.rd + ((16u * q) ^ io.rswz));
                 const uint32_t j = jb + 16u * q;
+                if (!whole && !(j < jend && j + 16 > j0)) return false;
+                const uint4 v = *reinterpret_cast<const uint4*>(io.rd + ((16u * q) ^ io.rswz));
                 if (!PREFIX) {
                     const uint32_t h0 = hits;
                     if (whole) kmp_chunk_count<false, false>(v, j, j0, jend, st, hits, idw);
-                    else if (j < jend && j + 16 > j0) kmp_chunk_count<true, false>(v, j, j0, jend, st, hits, idw);
+                    else kmp_chunk_count<true, false>(v, j, j0, jend, st, hits, idw);
                     return hits != h0;
                 } else {
                     uint32_t hm = 0;
                     if (whole) kmp_chunk_count<false, true>(v, j, j0, jend, st, hm, idw);
-                    else if (j < jend && j + 16 > j0) kmp_chunk_count<true, true>(v, j, j0, jend, st, hm, idw);
+                    else kmp_chunk_count<true, true>(v, j, j0, jend, st, hm, idw);
                     const bool seen = hm != 0;
                     while (hm) {  // the prefix ends at byte j+b: verify P[w..m)
                         const uint32_t b = __builtin_ctz(hm);
@@ -1565,7 +1563,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
                 // costs more than it saves: the wave counts directly while an eighth of its lanes
                 // saw one in the last half
                 dense = __popcll(__ballot(seen)) >= 8;
-            } else {
+            } else if (jb < jend && jb + 64u > j0) {  // an end of the run lies in this half
 #pragma unroll 1
                 for (uint32_t q = 0; q < 4; ++q) {
                     const uint32_t j = jb + 16u * q;
@@ -1586,7 +1584,6 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
             if (k + 1 < nlines) LINE_FETCH(gbase, blk, (k + 1) * kRunLine);  // wave-uniform
             half(k * kRunLine + 64u);
         }
-        if (ghost) hits = hits_before;
     }
     flush_hits(hits, a.count, smem);
 }
@@ -2160,7 +2157,7 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
 {
     const uint32_t m = a.m;
     const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));  // the transition table of kmp_runs (api.cpp build_blob)
-    uint32_t w = m < kKmpWindow ? m : kKmpWindow;           // bytes the automaton recognises; a run re-scans w-1
+    uint32_t w = kmp_window(m);                             // bytes the automaton recognises; a run re-scans w-1
     const uint32_t rows = w < 63 ? 4 * w + 2 : 256;         // up to the absorbing row Z
 #ifdef SMARTGPU_AB
     const bool links = g_tune[3] == 2;  // failure links

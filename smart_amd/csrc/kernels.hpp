@@ -20,7 +20,12 @@ constexpr uint32_t kPatternBytes = 4224;        // pattern slot in the plan blob
 constexpr int kResultSlots = 4096;
 constexpr uint32_t kSoWindow = 29;     // SO/SA: bytes of the pattern so_runs keeps in its 32-bit state (four steps of the
                                        // recurrence at once need three bits of headroom); longer patterns: prefix + verification
-constexpr uint32_t kKmpWindow = 254;   // KMP (kmp_runs): states 0..w plus the absorbing accept row are u8 ids: w = min(m, 254)
+constexpr uint32_t kKmpWindow = 254;   // KMP (kmp_runs): states 0..w plus the absorbing accept row are u8 ids: the whole pattern up to 254 bytes
+// Longer patterns: the automaton of this prefix, hits verified.  A run re-scans w-1 bytes: with the 254-byte prefix of
+// round 1 that was 6 % of a 4 KiB run; measured on 1 GiB, m = 256 .. 4096: 0.200-0.219 ms (254), 0.192-0.22 (126),
+// 0.188-0.212 (62) on rand128, the same order on English and rand2.  62 keeps the ids 4s (tables.cpp).
+constexpr uint32_t kKmpPrefix = 62;
+constexpr uint32_t kmp_window(uint32_t m) { return m <= kKmpWindow ? m : kKmpPrefix; }
 constexpr uint32_t kKmpQBytes = 272;   // kmp_runs: after the transitions, Q[s] = P[s..s+4) for 64 states (LDS), thr = 4K, 12 bytes of padding
 constexpr uint32_t kKmpDfaMaxM = 255;  // KMP: the automaton's states are u8, so its (w+1)*256-byte transition
                                        // table (<= 64 KB of LDS) recognises w = min(m, 255) bytes; longer
