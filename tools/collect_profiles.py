@@ -51,7 +51,7 @@ def main():
         if not os.path.isdir(sub):
             continue
         counter = "FETCH_SIZE" if "_fetch_" in os.path.basename(sub) else "WRITE_SIZE"
-        algo = os.path.basename(sub).rsplit("_", 1)[1]
+        algo = os.path.basename(sub).rsplit("_", 1)[1]  # hor, kmp, ... or kmp-sigma2, kmp-english (gpu_round.sh pmc)
         for kern, vals in sorted(pmc_rows(sub, counter).items()):
             if not kern.startswith(("void sg::", "sg::")):
                 continue
@@ -69,6 +69,15 @@ def main():
                 return r[4]
         return None
 
+    def scan_kernel(algo):
+        """the scan kernel that pass's bench ran most often: its name without template arguments"""
+        best = None
+        for r in rows:
+            name = r[1].split("sg::", 1)[1].split("<")[0].split("(")[0]
+            if r[0] == algo and r[2] == "FETCH_SIZE" and (name.endswith(("_scan", "_runs", "_scan_bp"))) and (best is None or r[3] > best[1]):
+                best = (name, r[3])
+        return best[0] if best else None
+
     # the kernel source the session ran: the sha256 gpu_round.sh took on the box; a session without one is bound
     # to the COMMITTED kernels.hip (the working tree may have moved on since the call was started)
     commit = subprocess.run(["git", "-C", here, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
@@ -82,10 +91,15 @@ def main():
         sha = hashlib.sha256(committed).hexdigest()
     traffic = {"_source": {"kernels_hip_sha256": sha, "commit": commit,
                            "summary": f"profiles/{rnd}/{prefix}_bench_pmc_summary.csv"}}
-    for algo, kern in (("hor", "hor_scan"), ("kmp", "kmp_runs"), ("so", "so_runs"), ("epsm", "packed_scan")):
-        fe, wr = mean(algo, kern, "FETCH_SIZE"), mean(algo, kern, "WRITE_SIZE")
+    for algo in sorted({r[0] for r in rows}):
+        kern = scan_kernel(algo)
+        if kern is None:
+            continue
+        fe, wr = mean(algo, "sg::" + kern, "FETCH_SIZE"), mean(algo, "sg::" + kern, "WRITE_SIZE")
+        name, _, variant = algo.partition("-")  # bench.py's workload key: <algo>_m<m>_sigma<s>_gib<g> / <algo>_m<m>_english_gib<g>
+        key = "%s_m32_%s_gib1" % (name, variant if variant else "sigma128")
         if fe is not None and wr is not None:
-            traffic.setdefault(kern, {})["%s_m32_sigma128_gib1" % algo] = int(round(2 * fe * 1024 + wr * 1024))
+            traffic.setdefault(kern, {})[key] = int(round(2 * fe * 1024 + wr * 1024))
     probe = mean("hor", "probe_read", "FETCH_SIZE")
     traffic["_how"] = (
         "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --algo <a> --steps 5 "

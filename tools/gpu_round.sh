@@ -16,10 +16,14 @@ step "bench" bash -c "timeout -k 10 900 python bench.py > '$OUT/bench.json' 2> '
 cd /tmp
 step "rocprofv3 stats" bash -c "timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d '$OUT/prof_stats' -- python3 '$ROOT/bench.py' --steps 20 --warmup 5 --no-cpu --no-sweep > '$OUT/prof_stats.log' 2>&1"
 find "$OUT/prof_stats" -name "*kernel_stats.csv" | head -1 | xargs -r head -8
-for ALGO in hor kmp so epsm; do
-  step "rocprofv3 pmc FETCH_SIZE $ALGO" bash -c "timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d '$OUT/prof_pmc_fetch_$ALGO' -- python3 '$ROOT/bench.py' --algo $ALGO --steps 5 --warmup 2 --no-cpu --no-sweep > '$OUT/prof_pmc_fetch_$ALGO.log' 2>&1"
-  step "rocprofv3 pmc WRITE_SIZE $ALGO" bash -c "timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d '$OUT/prof_pmc_write_$ALGO' -- python3 '$ROOT/bench.py' --algo $ALGO --steps 5 --warmup 2 --no-cpu --no-sweep > '$OUT/prof_pmc_write_$ALGO.log' 2>&1"
-done
+pmc() {  # pmc <name> <bench args...>: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM section)
+  NAME=$1; shift
+  step "rocprofv3 pmc FETCH_SIZE $NAME" bash -c "timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d '$OUT/prof_pmc_fetch_$NAME' -- python3 '$ROOT/bench.py' $* --steps 5 --warmup 2 --no-cpu --no-sweep > '$OUT/prof_pmc_fetch_$NAME.log' 2>&1"
+  step "rocprofv3 pmc WRITE_SIZE $NAME" bash -c "timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d '$OUT/prof_pmc_write_$NAME' -- python3 '$ROOT/bench.py' $* --steps 5 --warmup 2 --no-cpu --no-sweep > '$OUT/prof_pmc_write_$NAME.log' 2>&1"
+}
+for ALGO in hor kmp so epsm; do pmc $ALGO --algo $ALGO; done
+# the serial and packed kernels on the other kinds of text: a binary alphabet, the English corpus
+for ALGO in kmp so epsm; do pmc $ALGO-sigma2 --algo $ALGO --sigma 2; pmc $ALGO-english --algo $ALGO --corpus english; done
 cd "$ROOT"
 find "$OUT" -name "*.csv" -size +2M -delete   # keep the merge under the 64 MiB cap
 ls "$OUT"
