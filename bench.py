@@ -260,12 +260,19 @@ def main():
     oplans = []
     for j in range(K):
         # a kernel of another family than the one that produced the count
-        other = "kmp" if plans[W + j].kernel_name == "packed_scan" else "epsm"
-        if other == algo:
-            other = "so"
+        # (the packed matcher, the KMP automaton, Shift-Or: the first whose plan for THIS pattern leads elsewhere —
+        # on a binary text EPSM's own plan counts on so_runs too)
+        pl = None
+        for other in ("epsm", "kmp", "so"):
+            if other == algo:
+                continue
+            cand = Plan(other, pats[W + j][1], device=local_rank)
+            if cand.kernel_name != plans[W + j].kernel_name:
+                pl = cand
+                break
+            cand.free()
+        assert pl is not None, (plans[W + j].kernel_name, algo)
         others.append(other)
-        pl = Plan(other, pats[W + j][1], device=local_rank)
-        assert pl.kernel_name != plans[W + j].kernel_name, (pl.kernel_name, algo, other)
         pl.set_result_buffer(check.data_ptr() + 8 * j, 1)
         pl.launch(text, slot=0)
         oplans.append(pl)

@@ -523,7 +523,10 @@ def test_pattern_set_in_one_call(oracle):
         sub = [oracle.search("bf", p, T[off:off + nn]) for p in pats]
         for a in ("hor", "kmp", "so", "epsm"):
             assert smart_amd.search_batch(a, pats, text, off=off, n=nn)[0].tolist() == sub, (a, m)
-    # 300 KMP patterns: 40 MB of tables through a 32 MB staging buffer; the arena grows once
+    # 560 KMP patterns of 200 bytes (full 64 KB tables): 39 MB of blobs through the 32 MB staging buffer in two copies;
+    # the arena grows once
+    big = [T[k:k + 200].copy() for k in rng.integers(0, n - 200, 560)]
+    assert smart_amd.search_batch("kmp", big, text)[0].tolist() == [oracle.search("bf", p, T) for p in big]
     pats = [T[k:k + 32].copy() for k in rng.integers(0, n - 32, 300)]
     want = [oracle.search("bf", p, T) for p in pats]
     assert smart_amd.search_batch("kmp", pats, text)[0].tolist() == want
@@ -561,3 +564,28 @@ def test_small_texts_on_the_runs_kernels(oracle):
             got = gpu_counts(P, text, algos=("kmp", "so", "sa"), off=off, n=nn)
             assert all(v == sub for v in got.values()), (sigma, n, m, got, sub)
         text.free()
+
+
+def test_runs_kernels_where_the_text_does_not_fill_the_runs(oracle):
+    """Lengths that leave the last run of kmp_runs / so_runs with one start position, half of them, or the last
+    group of 64 runs partly empty, ranges that start inside a run, and run lengths that the balancing has to round
+    (kernels.hip balanced_run_len, first_group; tools/nvar_probe.py times the same cases)."""
+    n = (1 << 22) + 9000
+    T = oracle.gen_text(SEED2 + 5, 4, 0, n)  # a small alphabet: the ends of the runs see occurrences
+    text = Text.upload(T)
+    rng = np.random.default_rng(3)
+    for m in (5, 8, 62, 63, 200, 255, 300, 4096):
+        P = T[777_000:777_000 + m].copy()
+        for sub in ((1 << 22) + m - 1, (1 << 22) + m - 1 - 127, (1 << 22) - 1, (1 << 22) + 1, 4_000_001, 3_333_333, 1_000_000 + m, 65_537):
+            for off in (0, 1, 4097, 123_457):
+                nn = min(sub, n - off)
+                want = oracle.search("bf", P, T[off:off + nn])
+                for a in ("kmp", "so", "sa"):
+                    assert smart_amd.search(a, P, text, off=off, n=nn)[0] == want, (a, m, sub, off)
+    # a pattern whose own end is the text's end, and one byte less of text
+    for m in (8, 300):
+        P = T[n - m:].copy()
+        for a in ("kmp", "so"):
+            assert smart_amd.search(a, P, text)[0] == oracle.search("bf", P, T)
+            assert smart_amd.search(a, P, text, off=0, n=n - 1)[0] == oracle.search("bf", P, T[:n - 1])
+    text.free()
