@@ -384,10 +384,10 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
     //    dwords in most rows there (rand4 64-72 %, English below 32 bytes 70-73 %, rand32 short 72-76 %); so_runs
     //    does the same work whatever the bytes are and since round 2 runs at 75-81 % on all of them (English from 32
     //    bytes on: 79-80 % both).  On random text over a large alphabet symbols do not repeat and nothing changes.
-    //  * 16+ bytes whose first dword says next to nothing about where the pattern occurs (two or three symbols:
+    //  * 8+ bytes whose first dword says next to nothing about where the pattern occurs (two to four symbols:
     //    every lane of the packed matcher keeps a candidate through all four fingerprint dwords, every skip is a byte
     //    or two): the chance that 4 text bytes drawn like the pattern's own equal P[0..4), times the 16 alignments a
-    //    lane tests, is 0.15 or more.
+    //    lane tests, is 0.03 or more (8+ bytes; up to four symbols).
     // SO and SA keep their own serial kernel, KMP its own from 5 bytes on (below that kmp_runs has only its lookup per
     // byte, and at 2 bytes walks every fourth half twice to count: 54-69 % on rand128 against so_runs' 76-78 %),
     // Karp-Rabin its own from 16 bytes on, EPSM its packed matcher (it IS that algorithm).
@@ -396,12 +396,15 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
         //   the every-byte kernels win there; so_runs and the packed matcher are equal on rand128 (76-77 %), so_runs
         //   ahead on everything else (rand256, rand32, English at m = 2, 4: 78-81 % against 67-76 %).
         bool to_so = (algo == SMARTGPU_KR || algo == SMARTGPU_KMP) ? true : (repeats || repeats_short || m <= sg::short_pattern_max_m(algo)) && algo != SMARTGPU_EPSM;
-        if (!to_so && m >= 16) {
+        if (!to_so && m >= 8) {  // (8 bytes of distinct symbols estimate 16/8^4 = 0.004: below that the histogram says nothing)
             uint32_t cnt[256] = {0};
             for (uint32_t i = 0; i < m; ++i) ++cnt[P[i]];
             double pass = 16.0;
             for (uint32_t i = 0; i < 4; ++i) pass *= static_cast<double>(cnt[P[i]]) / m;
-            to_so = pass >= 0.15;  // rand2: 1.0, rand3: 0.2 (so_runs 63-68 % vs 54-63 %), rand4: 0.06
+            // rand2: 1.0, rand3: 0.2, rand4: 0.06, rand8: 0.004.  Round 1 drew the line at 0.15 (so_runs then ran at
+            // 63-68 %); at 75-81 % it also beats the packed matcher on rand4 (EPSM there: 59-67 %, a second
+            // fingerprint dword in nearly every row), not on rand8 and up.
+            to_so = pass >= 0.03;
         }
         if (to_so) {
             blob.resize((blob.size() + 15) & ~size_t(15), 0);

@@ -244,7 +244,11 @@ def test_kernel_choice_follows_the_pattern(oracle):
         for a in engine.ALGOS:
             want = {"kmp": "kmp_runs", "kr": "hor_scan_bp"}.get(a, "so_runs")
             assert kf(a, two[:m]) == want, (a, m)
-    assert kf("hor", two[:12]) == "so_runs" and kf("epsm", two[:12]) == "packed_scan"
+    assert kf("hor", two[:12]) == "so_runs" and kf("epsm", two[:12]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"
+    # ... and, since so_runs runs at 75-81 %, on four: EPSM from 8 bytes on (the skip algorithms are there by rule 1)
+    assert kf("epsm", four[:8]) == "so_runs" and kf("epsm", four[:64]) == "so_runs" and kf("epsm", four[:4]) == "packed_scan"
+    eight = oracle.gen_text(9, 8, 0, 5000)
+    assert kf("epsm", eight[:64]) == "packed_scan" and kf("epsm", rnd[:8]) == "packed_scan"
     # the serial automata never move — KMP from 5 bytes on (below that kmp_runs has no four-bytes-at-a-time form)
     for P in (rnd[:32], eng[:32], four[:32], rnd[:5], two[:5]):
         assert kf("kmp", P) == "kmp_runs" and kf("so", P) == "so_runs" and kf("sa", P) == "so_runs"
