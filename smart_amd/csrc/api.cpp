@@ -388,10 +388,12 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
     //    every lane of the packed matcher keeps a candidate through all four fingerprint dwords, every skip is a byte
     //    or two): the chance that 4 text bytes drawn like the pattern's own equal P[0..4), times the 16 alignments a
     //    lane tests, is 0.03 or more (8+ bytes; up to four symbols).
-    // SO and SA keep their own serial kernel, KMP its own from 5 bytes on (below that kmp_runs has only its lookup per
-    // byte, and at 2 bytes walks every fourth half twice to count: 54-69 % on rand128 against so_runs' 76-78 %),
+    // SO and SA keep their own serial kernel, KMP its own from 9 bytes on — where its automaton can have the borderless
+    // states 0..4 that the four-bytes-at-a-time form for natural language and medium alphabets needs (kmp_runs: K + 4 < w).
+    // Below that kmp_runs has its state-0 form from 5 bytes and a lookup per byte otherwise, and counts frequent
+    // occurrences byte by byte: m = 8: 61-72 % against so_runs' 74-81 % on every corpus; m = 2: 54 % against 76-78 %.
     // Karp-Rabin its own from 16 bytes on, EPSM its packed matcher (it IS that algorithm).
-    if ((algo != SMARTGPU_KMP || m < 5) && algo != SMARTGPU_SO && algo != SMARTGPU_SA && (algo != SMARTGPU_KR || m < 16)) {
+    if ((algo != SMARTGPU_KMP || m < 9) && algo != SMARTGPU_SO && algo != SMARTGPU_SA && (algo != SMARTGPU_KR || m < 16)) {
         // * Short patterns (below the algorithm's measured crossover with its own skip loop, kernels.hip packed_max_m):
         //   the every-byte kernels win there; so_runs and the packed matcher are equal on rand128 (76-77 %), so_runs
         //   ahead on everything else (rand256, rand32, English at m = 2, 4: 78-81 % against 67-76 %).

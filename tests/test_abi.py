@@ -249,10 +249,10 @@ def test_kernel_choice_follows_the_pattern(oracle):
     assert kf("epsm", four[:8]) == "so_runs" and kf("epsm", four[:64]) == "so_runs" and kf("epsm", four[:4]) == "packed_scan"
     eight = oracle.gen_text(9, 8, 0, 5000)
     assert kf("epsm", eight[:64]) == "packed_scan" and kf("epsm", rnd[:8]) == "packed_scan"
-    # the serial automata never move — KMP from 5 bytes on (below that kmp_runs has no four-bytes-at-a-time form)
-    for P in (rnd[:32], eng[:32], four[:32], rnd[:5], two[:5]):
+    # the serial automata never move — KMP from 9 bytes on (below that its automaton has no room for the 0..K form)
+    for P in (rnd[:32], eng[:32], four[:32], rnd[:9], two[:9]):
         assert kf("kmp", P) == "kmp_runs" and kf("so", P) == "so_runs" and kf("sa", P) == "so_runs"
-    assert kf("kmp", rnd[:4]) == "so_runs" and kf("kmp", eng[:2]) == "so_runs" and kf("kmp", rnd[:1]) == "so_runs"
+    assert kf("kmp", rnd[:8]) == "so_runs" and kf("kmp", eng[:2]) == "so_runs" and kf("kmp", rnd[:1]) == "so_runs"
     assert kf("epsm", rnd[:32]) == "packed_scan" and kf("epsm", eng[:32]) == "packed_scan"  # EPSM is the packed matcher
     # tune(0,1): every algorithm on its own kernel
     engine.tune(0, 1)
@@ -286,11 +286,11 @@ def test_product_library_carries_no_superseded_kernels():
     try:
         assert b"A/B" in L.smartgpu_version()
         engine.tune(3, 3)
-        assert smart_amd.kernel_for("kmp", b"abcdabcd") == "kmp_runs1"
+        assert smart_amd.kernel_for("kmp", b"abcdabcdabcd") == "kmp_runs1"
         engine.tune(3, 0)
         engine.tune(6, 2)
         assert smart_amd.kernel_for("so", b"abcdabcd") == "so_runs64"
         engine.tune(6, 0)
     finally:
         engine.use_library()
-    assert smart_amd.kernel_for("kmp", b"abcdabcd") == "kmp_runs"
+    assert smart_amd.kernel_for("kmp", b"abcdabcdabcd") == "kmp_runs"
