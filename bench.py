@@ -22,7 +22,7 @@ their code; started under torchrun (the driver's way) it is one of the ranks.
 The text is N x --gib GiB sharded by byte offset with an (m-1)-byte overlap; the
 K counts are summed with ONE RCCL all-reduce inside the timed region
 ("scaling": "weak").  `--gib 4` gives every GPU the 4 GiB shard of BASELINE
-configs 4-5.
+configs 4-5; `--scaling strong` splits ONE text of --gib GiB over the ranks.
 
 After the timed region every count is checked: against a kernel of a different
 family (the KMP automaton when the timed plans run on the packed matcher, the
@@ -113,7 +113,9 @@ def main():
     ap.add_argument("--algo", default="hor")
     ap.add_argument("--plen", dest="m", type=int, default=32, help="pattern length m")
     ap.add_argument("--sigma", type=int, default=128)
-    ap.add_argument("--gib", type=float, default=1.0, help="text GiB per GPU")
+    ap.add_argument("--gib", type=float, default=1.0, help="text GiB per GPU (--scaling strong: of the whole text)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (the contract's default): --gib per GPU; strong: one text of --gib GiB split over the ranks")
     ap.add_argument("--corpus", default="rand", help="rand (counter-based rand<sigma>) or english "
                     "(tests/golden/english_bible_world192.txt.xz tiled to --gib per GPU, BASELINE config 4)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -181,7 +183,7 @@ def main():
         return t
 
     K, W, m, algo = args.steps, args.warmup, args.m, args.algo
-    shard = int(args.gib * (1 << 30))
+    shard = int(args.gib * (1 << 30)) // (world if args.scaling == "strong" else 1)
     total_n = shard * world
     # rank r owns start positions [r*shard, (r+1)*shard) (the last rank stops at
     # total_n - m); it holds m-1 extra bytes so those windows are complete
@@ -353,10 +355,10 @@ def main():
         bytes_per_launch = local_len                       # algorithmic bytes: every text byte once
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         if english is not None:
-            workload = "%s m=%d, English (bible.txt||world192.txt, %d B) tiled to %.2f GiB per GPU" % (algo.upper(), m, len(english), args.gib)
+            workload = "%s m=%d, English (bible.txt||world192.txt, %d B) tiled to %.2f GiB per GPU" % (algo.upper(), m, len(english), shard / (1 << 30))
             key = "%s_m%d_english_gib%g" % (algo, m, args.gib)
         else:
-            workload = "%s m=%d, %.2f GiB rand%d per GPU" % (algo.upper(), m, args.gib, args.sigma)
+            workload = "%s m=%d, %.2f GiB rand%d per GPU" % (algo.upper(), m, shard / (1 << 30), args.sigma)
             key = "%s_m%d_sigma%d_gib%g" % (algo, m, args.sigma, args.gib)
         traffic, traffic_source = load_traffic(main_kernel, key)
         out = {
@@ -365,7 +367,7 @@ def main():
             "unit": "GB/s",
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed * 1e3 / K, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic" if english is None else "reference corpus (englishTexts), tiled",
             "config": {"workload": workload, "algorithm": algo, "m": m, "sigma": args.sigma if english is None else None,
                        "text_bytes_per_gpu": local_len, "patterns": K,
