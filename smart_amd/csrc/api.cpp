@@ -826,6 +826,7 @@ bool batch_reserve(DeviceCtx* d, size_t blob_bytes, size_t k)
 
 struct BatchPlan { uint32_t halo, prefer_packed, sparse, so_off; size_t off; };
 constexpr uint64_t kOneGridMaxText = 32ull << 20;  // pattern sets over texts up to this size run as ONE grid per kernel
+constexpr uint32_t kBatchMaxPatterns = 1u << 20;    // per call (the launch order of a set sits in the staging buffer's tail)
 
 // Build the K blobs on the host and place them in the device's arena; pre_ms[k] = host table construction of
 // pattern k + its share of the upload.  plans[k].off = offset of blob k in the arena.
@@ -966,6 +967,7 @@ int smartgpu_search_batch64(int algo, const uint8_t* const* P, uint32_t m, uint3
                             uint64_t off, uint64_t n, uint64_t* counts, double* pre_ms, double* run_ms, double* batch_ms)
 {
     if (!P || K < 1 || !counts) { set_error("batch: P/counts NULL or K = 0"); return SMARTGPU_ERR_ARG; }
+    if (K > kBatchMaxPatterns) { set_error("batch: %u patterns in one set (at most %u)", K, kBatchMaxPatterns); return SMARTGPU_ERR_ARG; }
     const int rc = check_search_args(algo, P[0], m, text, off, n);
     if (rc != SMARTGPU_OK) return rc;
     DeviceCtx* d = device_ctx(text->device);
@@ -1195,6 +1197,7 @@ int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint
 {
     if (!text) { set_error("text handle is NULL"); return SMARTGPU_ERR_ARG; }
     if (!P || K < 1 || !counts || !P[0]) { set_error("batch: P/counts NULL or K = 0"); return SMARTGPU_ERR_ARG; }
+    if (K > kBatchMaxPatterns) { set_error("batch: %u patterns in one set (at most %u)", K, kBatchMaxPatterns); return SMARTGPU_ERR_ARG; }
     if (algo < 0 || algo >= SMARTGPU_NUM_ALGOS) { set_error("unknown algorithm id %d", algo); return SMARTGPU_ERR_ARG; }
     if (m < min_pattern(algo)) { set_error("%s: not applicable for m < %u", kAlgoNames[algo], min_pattern(algo)); return SMARTGPU_NA; }
     if (m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return SMARTGPU_ERR_ARG; }
