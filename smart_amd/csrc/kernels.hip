@@ -2103,6 +2103,16 @@ static uint64_t runs_grid(uint64_t nruns, int num_cus)
     return want < spread ? want : spread;
 }
 
+// SMARTGPU_DEBUG=1 in the environment: the geometry of every launch of a runs kernel on stderr (tools/nvar_probe.py)
+static void trace_runs(const char* kernel, const ScanArgs& a, uint64_t run_len, const TileRange& tr, uint64_t grid)
+{
+    static const bool on = getenv("SMARTGPU_DEBUG") != nullptr;
+    if (on)
+        fprintf(stderr, "%s: starts [%llu, %llu) runs of %llu bytes: %llu from run %llu, %llu workgroups x %u patterns\n", kernel,
+                (unsigned long long)a.s_begin, (unsigned long long)a.s_end, (unsigned long long)run_len,
+                (unsigned long long)tr.count, (unsigned long long)tr.first, (unsigned long long)grid, g_batch.count);
+}
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel), not per launch
 static void allow_lds(const void* kernel, size_t lds)
 {
@@ -2127,6 +2137,7 @@ static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus,
     if (tr.count == 0) return hipSuccess;
     const size_t lds = 65536 + kRunWaves * (size_t)kLineSlab;
     const uint64_t grid = runs_grid(tr.count, num_cus);
+    trace_runs("so_runs", a, L, tr, grid);
 #ifdef SMARTGPU_AB
 #define SG_SO_RUNS1(L_, A_)                                                                               \
     do {                                                                                                 \
@@ -2197,7 +2208,7 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
     const uint64_t grid = runs_grid(tr.count, num_cus);
-    if (getenv("SMARTGPU_DEBUG")) fprintf(stderr, "kmp_runs: span [%llu, %llu) L %llu runs %llu first %llu grid %llu\n", (unsigned long long)a.s_begin, (unsigned long long)a.s_end, (unsigned long long)L, (unsigned long long)tr.count, (unsigned long long)tr.first, (unsigned long long)grid);
+    trace_runs("kmp_runs", a, L, tr, grid);
 #define SG_KMP_RUNS(K_, OFF_)                                                                            \
     do {                                                                                                 \
         if (lds > 64 * 1024) allow_lds(reinterpret_cast<const void*>(K_), lds);                          \
