@@ -500,7 +500,9 @@ def run_sweep(text128, device):
             "min_frac": {"rand128_m4to256_plan_choice": min(north),
                          "config3_plan_choice": min(plan(3)), "config4_english_plan_choice": min(plan(4)),
                          "config5_plan_choice": min(plan(5)),
-                         "all_cells": min(c["frac"] for c in cells)},
+                         "plan_choice_all_cells": min(c["frac"] for c in cells if not c.get("own_kernel")),
+                         # what the plans route AWAY from: a skip loop on a binary text shifts by a byte or two
+                         "own_kernel_cells": min([c["frac"] for c in cells if c.get("own_kernel")] or [None])},
             "note": "config = BASELINE.json configuration the cell belongs to (4: the English unit tiled to 1 GiB, 5: one 1 GiB "
                     "shard per alphabet; their 4 GiB sizes: profiles/ sweeps, tests/test_configs_gpu.py); "
                     "1 GiB per cell; ms = HIP events over %d launches (%d patterns x %d); frac = 2^30 B / ms / 8 TB/s; "
