@@ -772,21 +772,18 @@ int smartgpu_search64(int algo, const uint8_t* P, uint32_t m, const smartgpu_tex
 {
     const int rc = check_search_args(algo, P, m, text, off, n);
     if (rc != SMARTGPU_OK) return rc;
-    smartgpu_plan* p = smartgpu_plan_create(algo, P, m, text->device);  // preprocessing phase
-    if (!p) return SMARTGPU_ERR_HIP;
+    // a pattern set of one: tables through the device's arena and staging buffer (no allocation per call — a plan's
+    // two hipMalloc and its memset were most of the 25-30 us a call cost around a 3 us kernel), one launch, one read-back
+    const uint8_t* set[1] = {P};
     uint64_t c = 0;
-    double kms = 0.0;
-    const double t0 = now_ms();
-    int r = smartgpu_plan_launch(p, text, off, n, 0, 1);                 // searching phase
-    if (r == SMARTGPU_OK) r = smartgpu_plan_result(p, 0, &c, &kms);
-    const double wall = now_ms() - t0;
-    g_last_pre_ms = p->pre_ms;
-    g_last_run_ms = wall;  // launch -> count on host, the run_time analogue (main.h:29,31)
-    smartgpu_plan_free(p);
+    double pre = 0.0, wall = 0.0;
+    const int r = smartgpu_search_batch64(algo, set, m, 1, text, off, n, &c, &pre, nullptr, &wall);
     if (r != SMARTGPU_OK) return r;
+    g_last_pre_ms = pre;
+    g_last_run_ms = wall;  // launch -> count on host, the run_time analogue (main.h:29,31)
     if (count) *count = c;
-    if (pre_ms) *pre_ms = g_last_pre_ms;
-    if (run_ms) *run_ms = g_last_run_ms;
+    if (pre_ms) *pre_ms = pre;
+    if (run_ms) *run_ms = wall;
     return SMARTGPU_OK;
 }
 
@@ -825,8 +822,13 @@ bool batch_reserve(DeviceCtx* d, size_t blob_bytes, size_t k)
 }
 
 struct BatchPlan { uint32_t halo, prefer_packed, sparse, so_off; size_t off; };
+// the staging buffer of a set of K patterns: [table blobs ...][K argument records][K launch-order indices]
+size_t batch_tail_offset(const DeviceCtx* d, uint32_t K)
+{
+    return (d->pinned_bytes - static_cast<size_t>(K) * (4 + sizeof(sg::BatchItem))) & ~size_t(63);
+}
 constexpr uint64_t kOneGridMaxText = 32ull << 20;  // pattern sets over texts up to this size run as ONE grid per kernel
-constexpr uint32_t kBatchMaxPatterns = 1u << 20;    // per call (the launch order of a set sits in the staging buffer's tail)
+constexpr uint32_t kBatchMaxPatterns = 1u << 18;    // per call (argument records and launch order of a set sit in the staging buffer's tail: 9 of its 32 MB)
 
 // Build the K blobs on the host and place them in the device's arena; pre_ms[k] = host table construction of
 // pattern k + its share of the upload.  plans[k].off = offset of blob k in the arena.
@@ -839,16 +841,18 @@ int batch_upload(DeviceCtx* d, int algo, const uint8_t* const* P, uint32_t m, ui
     // the blobs of one algorithm and one length are equally long (multiples of 256): size the arena from the first
     if (!P[0]) { set_error("pattern 0 is NULL"); return SMARTGPU_ERR_ARG; }
     build_blob(blob, algo, P[0], m, &plans[0].halo, &plans[0].prefer_packed, &plans[0].sparse, &plans[0].so_off);
-    const size_t room = d->pinned_bytes - static_cast<size_t>(K) * 4;  // the tail of the staging buffer holds the launch order
+    const size_t room = batch_tail_offset(d, K);  // the tail of the staging buffer holds the set's argument records and launch order
     if (blob.size() > room) { set_error("a table blob of %zu bytes exceeds the staging buffer", blob.size()); return SMARTGPU_ERR_NOMEM; }
     if (!batch_reserve(d, (blob.size() + 4096) * K + 256 + K * sizeof(sg::BatchItem), K)) return SMARTGPU_ERR_NOMEM;
     double up_total = 0.0;
     size_t total = 0, fill = 0, fill_off = 0;  // staging holds `fill` bytes that belong at arena offset fill_off
-    auto flush = [&]() -> bool {
+    // the copy is waited for only where the staging buffer is filled again in this call: the launches that follow are
+    // ordered behind it on the stream, and every caller ends with a synchronisation before the buffer is reused
+    auto flush = [&](bool more) -> bool {
         if (!fill) return true;
         const double t_up = now_ms();
         const bool ok = hipMemcpyAsync(d->arena + fill_off, d->pinned, fill, hipMemcpyHostToDevice, d->stream) == hipSuccess &&
-                        hipStreamSynchronize(d->stream) == hipSuccess;
+                        (!more || hipStreamSynchronize(d->stream) == hipSuccess);
         up_total += now_ms() - t_up;
         fill_off += fill;
         fill = 0;
@@ -862,14 +866,14 @@ int batch_upload(DeviceCtx* d, int algo, const uint8_t* const* P, uint32_t m, ui
             set_error("batch: the table arena (%zu bytes) is too small for this pattern set", d->arena_bytes);
             return SMARTGPU_ERR_NOMEM;
         }
-        if (fill + blob.size() > room && !flush()) { set_error("batch: table upload failed (%s)", hipGetErrorString(hipGetLastError())); return SMARTGPU_ERR_HIP; }
+        if (fill + blob.size() > room && !flush(true)) { set_error("batch: table upload failed (%s)", hipGetErrorString(hipGetLastError())); return SMARTGPU_ERR_HIP; }
         std::memcpy(d->pinned + fill, blob.data(), blob.size());  // straight into the staging buffer
         fill += blob.size();
         plans[k].off = total;
         total += blob.size();  // multiples of 256
         host_ms[k] = now_ms() - t0;
     }
-    if (!flush()) { set_error("batch: table upload failed (%s)", hipGetErrorString(hipGetLastError())); return SMARTGPU_ERR_HIP; }
+    if (!flush(false)) { set_error("batch: table upload failed (%s)", hipGetErrorString(hipGetLastError())); return SMARTGPU_ERR_HIP; }
     const double up_ms = up_total / K;
     if (pre_ms)
         for (uint32_t k = 0; k < K; ++k) pre_ms[k] = host_ms[k] + up_ms;
@@ -928,7 +932,8 @@ int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, u
     std::vector<uint32_t> order(K);
     for (uint32_t k = 0; k < K; ++k) order[k] = k;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
-    sg::BatchItem* host_items = reinterpret_cast<sg::BatchItem*>(d->pinned);
+    // (in the staging buffer's tail: its front may still be on its way to the arena — batch_upload does not wait)
+    sg::BatchItem* host_items = reinterpret_cast<sg::BatchItem*>(d->pinned + batch_tail_offset(d, K));
     for (uint32_t i = 0; i < K; ++i) {
         const BatchPlan& bp = plans[order[i]];
         const sg::ScanArgs pa = sg::prepare_scan_args(algo, batch_args(bp, d, m, text, off, n, d->batch_counts));
