@@ -10,9 +10,11 @@
  *     system("./source/bin/<algo> shared ...") (smart.c:140-146);
  *   - pre/search times come back as out-parameters instead of two 8-byte shm
  *     segments (main.h:28-37).
- * Report files: TXT (-txt), LaTeX (-tex) and XML (always), in the formats of
- * src/output.h:116-247; the HTML/PHP chart pages need SMART's RGraph assets and are
- * not produced.
+ * Report files: TXT (-txt), LaTeX (-tex), XML (always) and the PHP data array (-php) in the
+ * formats of src/output.h:49-247; the HTML page of every corpus (always) with its charts drawn
+ * as inline SVG — the reference's pages load the RGraph scripts of its results/ directory,
+ * which are not part of this project — and results/<code>/index.html linking the pages
+ * (outputINDEX, output.h:706-741).
  * Additions: -algo LIST, -data DIR, -gpu D, device-generated rand corpora when the
  * data directory has none, a GB/s column (stdout) and <GBS> element (XML).
  *
@@ -53,7 +55,7 @@ struct options {
     long tsize;        /* -tsize in bytes (smart.c:416: 1 MiB) */
     int minlen, maxlen;
     const int *lengths;
-    int occ, pre, dif, std, txt, tex;
+    int occ, pre, dif, std, txt, tex, php;
     int limit_ms;      /* -tb (smart.c:424: 300 ms) */
     int device;
     int gpus;          /* -gpus k: shard the text over k GPUs of this process, RCCL sum of the counts */
@@ -81,6 +83,7 @@ static void usage(void)
     printf("\t-std          also print the standard deviation\n");
     printf("\t-txt          write the result table as results/<code>/<corpus>.txt\n");
     printf("\t-tex          write it as a LaTeX tabular too\n");
+    printf("\t-php          write it as a PHP array (results/<code>/<corpus>.php) too\n");
     printf("\t-simple P T   one search of pattern P (<= 100 chars) in text T (<= 1000 chars)\n");
     printf("\t-algo LIST    comma separated algorithms out of hor,bm,kmp,so,bndm,epsm,sa,qs,tunedbm,raita,\n");
     printf("\t              hash3,hash5,hash8,sbndm,kr,bndml (default: all of them, or the ones marked #1 in\n");
@@ -452,12 +455,113 @@ static void write_xml(const struct options *o, const char *corpus, const char *c
     fclose(fp);
 }
 
+/* results/<code>/<corpus>.php: the table as a PHP array for SMART's result browser (reference:
+ * outputPHP, src/output.h:49-113): "PATT" => the lengths, "<ALGO>" => the mean times as strings
+ * ("VOID" where there is none), with -dif "<ALGO>.best" / "<ALGO>.worst", with -std "<ALGO>.std".
+ * Four decimals instead of the reference's two: a search of a 1 MiB text takes microseconds here. */
+static void write_php(const struct options *o, const char *corpus, const char *code,
+                      struct cell table[MAX_ALGOS][MAX_LENGTHS])
+{
+    char path[400];
+    snprintf(path, sizeof path, "results/%s/%s.php", code, corpus);
+    FILE *fp = fopen(path, "w");
+    if (!fp) { printf("\tError in writing file %s/%s.php\n", code, corpus); return; }
+    printf("\tSaving data on %s/%s.php\n", code, corpus);
+    fprintf(fp, "<?\n$%s = array(\n\t\"PATT\" => array(", corpus);
+    for (int il = 0; o->lengths[il] > 0; ++il)
+        if (o->lengths[il] >= o->minlen && o->lengths[il] <= o->maxlen) fprintf(fp, "\"%d\", ", o->lengths[il]);
+    fprintf(fp, "),\n");
+    for (int ia = 0; ia < o->nalgos; ++ia) {
+        char name[32];
+        upper(name, smartgpu_algo_name(o->algos[ia]));
+        for (int what = 0; what < 4; ++what) {  /* mean, best, worst, std */
+            if ((what == 1 || what == 2) && !o->dif) continue;
+            if (what == 3 && !o->std) continue;
+            fprintf(fp, "\t\"%s%s\" => array(", name, what == 0 ? "" : what == 1 ? ".best" : what == 2 ? ".worst" : ".std");
+            for (int il = 0; o->lengths[il] > 0; ++il) {
+                if (o->lengths[il] < o->minlen || o->lengths[il] > o->maxlen) continue;
+                const struct cell *c = &table[ia][il];
+                const double v = what == 0 ? c->mean : what == 1 ? c->best : what == 2 ? c->worst : c->std;
+                if (c->mean <= 0) fprintf(fp, (what == 1 || what == 2) ? "\"0.1\", " : "\"VOID\", ");
+                else fprintf(fp, "\"%.4f\", ", v);
+            }
+            fprintf(fp, "),\n");
+        }
+    }
+    fprintf(fp, ");\n?>");
+    fclose(fp);
+}
+
+/* results/<code>/index.html: one link per corpus page (reference: outputINDEX, src/output.h:706-741) */
+static void write_index(const char *code, const char *const *names, int ncorp)
+{
+    char path[400];
+    snprintf(path, sizeof path, "results/%s/index.html", code);
+    FILE *fp = fopen(path, "w");
+    printf("\tWriting %s/index.html\n", code);
+    if (!fp) { printf("\tError in writing file %s/index.html\n", code); return; }
+    fprintf(fp, "<!DOCTYPE html><html><head><meta charset=\"utf-8\"><title>SMART: experimental results %s</title></head>\n<body>"
+                "<h2>SMART: experimental results %s</h2>\n<table>\n", code, code);
+    for (int k = 0; k < ncorp; ++k)
+        fprintf(fp, "<tr><td><a href=\"%s.html\">Experimental results on %s</a></td></tr>\n", names[k], names[k]);
+    fprintf(fp, "</table></body></html>\n");
+    fclose(fp);
+}
+
+/* One line chart as inline SVG: a polyline per algorithm over the pattern lengths (equally spaced, as the
+ * reference's charts place them), the value of cell(ia, il) on a linear axis from 0. */
+static void svg_chart(FILE *fp, const struct options *o, struct cell table[MAX_ALGOS][MAX_LENGTHS], int gbs,
+                      const char *title, const char *unit)
+{
+    static const char *const colour[] = {"#1f77b4", "#d62728", "#2ca02c", "#9467bd", "#ff7f0e", "#8c564b", "#e377c2", "#7f7f7f",
+                                         "#bcbd22", "#17becf", "#393b79", "#ad494a", "#637939", "#7b4173", "#e6550d", "#3182bd"};
+    int cols[MAX_LENGTHS], nc = 0;
+    for (int il = 0; o->lengths[il] > 0; ++il)
+        if (o->lengths[il] >= o->minlen && o->lengths[il] <= o->maxlen) cols[nc++] = il;
+    double top = 0;
+    for (int ia = 0; ia < o->nalgos; ++ia)
+        for (int k = 0; k < nc; ++k) {
+            const struct cell *c = &table[ia][cols[k]];
+            const double v = c->mean > 0 ? (gbs ? c->gbs : c->mean) : 0;
+            if (v > top) top = v;
+        }
+    if (nc == 0 || top <= 0) return;
+    const int W = 760, H = 320, L = 60, R = 130, T = 30, B = 40;
+    const double dx = nc > 1 ? (double)(W - L - R) / (nc - 1) : 0;
+    fprintf(fp, "<h3>%s</h3>\n<svg xmlns=\"http://www.w3.org/2000/svg\" width=\"%d\" height=\"%d\" font-family=\"sans-serif\" font-size=\"11\">\n", title, W, H);
+    fprintf(fp, "<rect x=\"%d\" y=\"%d\" width=\"%d\" height=\"%d\" fill=\"none\" stroke=\"#999\"/>\n", L, T, W - L - R, H - T - B);
+    for (int g = 0; g <= 4; ++g) {  /* horizontal grid and the y axis' labels */
+        const double y = T + (H - T - B) * (1.0 - g / 4.0);
+        fprintf(fp, "<line x1=\"%d\" y1=\"%.1f\" x2=\"%d\" y2=\"%.1f\" stroke=\"#ddd\"/><text x=\"%d\" y=\"%.1f\" text-anchor=\"end\">%.4g</text>\n",
+                L, y, W - R, y, L - 6, y + 4, top * g / 4.0);
+    }
+    for (int k = 0; k < nc; ++k)
+        fprintf(fp, "<text x=\"%.1f\" y=\"%d\" text-anchor=\"middle\">%d</text>\n", L + dx * k, H - B + 16, o->lengths[cols[k]]);
+    fprintf(fp, "<text x=\"%d\" y=\"%d\" text-anchor=\"middle\">pattern length</text><text x=\"12\" y=\"%d\">%s</text>\n",
+            L + (W - L - R) / 2, H - 6, T - 10, unit);
+    for (int ia = 0; ia < o->nalgos; ++ia) {
+        char name[32];
+        upper(name, smartgpu_algo_name(o->algos[ia]));
+        const char *col = colour[ia % 16];
+        fprintf(fp, "<polyline fill=\"none\" stroke=\"%s\" stroke-width=\"1.5\" points=\"", col);
+        for (int k = 0; k < nc; ++k) {
+            const struct cell *c = &table[ia][cols[k]];
+            if (c->mean <= 0) continue;
+            fprintf(fp, "%.1f,%.1f ", L + dx * k, T + (H - T - B) * (1.0 - (gbs ? c->gbs : c->mean) / top));
+        }
+        fprintf(fp, "\"/>\n<line x1=\"%d\" y1=\"%d\" x2=\"%d\" y2=\"%d\" stroke=\"%s\" stroke-width=\"2\"/><text x=\"%d\" y=\"%d\">%s</text>\n",
+                W - R + 10, T + 8 + 14 * ia, W - R + 30, T + 8 + 14 * ia, col, W - R + 36, T + 12 + 14 * ia, name);
+    }
+    fprintf(fp, "</svg>\n");
+}
+
 /* results/<code>/<corpus>.html: the report page (reference: outputHTML2, src/output.h:443-633).
  * Same content — header block, one row per algorithm and one column per length, the best time
  * of a column in bold, the preprocessing time when -pre was given — as a self-contained page:
  * the reference's page draws its charts with the RGraph scripts and style sheet of its results/
- * directory, which are not part of this project; here the GB/s of each cell are listed under the
- * time instead. */
+ * directory, which are not part of this project; here the two charts (mean running time and GB/s
+ * over the pattern lengths, a line per algorithm) are inline SVG, and the GB/s and the kernel of
+ * each cell are listed under its time. */
 static void write_html(const struct options *o, const char *corpus, const char *code, long long n,
                        struct cell table[MAX_ALGOS][MAX_LENGTHS])
 {
@@ -497,8 +601,11 @@ static void write_html(const struct options *o, const char *corpus, const char *
         }
         fprintf(fp, "</tr>\n");
     }
-    fprintf(fp, "</table>\n<p>Running times in milliseconds (mean over %d patterns)%s.</p></body></html>\n", o->runs,
+    fprintf(fp, "</table>\n<p>Running times in milliseconds (mean over %d patterns)%s.</p>\n", o->runs,
             o->pre ? ", preprocessing times above them" : "");
+    svg_chart(fp, o, table, 0, "Running times", "ms");
+    svg_chart(fp, o, table, 1, "Text scanned per second", "GB/s");
+    fprintf(fp, "</body></html>\n");
     fclose(fp);
 }
 
@@ -546,7 +653,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "-std")) o.std = 1;
         else if (!strcmp(a, "-txt")) o.txt = 1;
         else if (!strcmp(a, "-tex")) o.tex = 1;
-        else if (!strcmp(a, "-php")) { /* PHP/HTML chart pages need SMART's RGraph assets: not provided */ }
+        else if (!strcmp(a, "-php")) o.php = 1;
         else if (!strcmp(a, "-short")) o.lengths = LEN_SHORT;
         else if (!strcmp(a, "-vshort")) o.lengths = LEN_VERY_SHORT;
         else if (!strcmp(a, "-data")) { if (!has1) { printf("%s", bad); return 0; } o.data_dir = argv[++i]; }
@@ -653,8 +760,10 @@ int main(int argc, char **argv)
         write_xml(&o, corpus, code, table); /* always, as smart.c:388 */
         write_html(&o, corpus, code, (long long)n, table); /* always, as smart.c:389 */
         if (o.tex) write_tex(&o, corpus, code, table);
+        if (o.php) write_php(&o, corpus, code, table);
         smartgpu_text_free(text);
     }
+    write_index(code, names, ncorp); /* smart.c:635,670 */
     free(T);
     return 0;
 }

@@ -69,7 +69,7 @@ def test_reference_cases_through_plugin_shape(algo):
 @pytest.mark.gpu
 def test_smart_report_lines(tmp_path):
     r = run("smart", "-text", "rand128", "-plen", "32", "32", "-pset", "5", "-occ", "-pre", "-dif", "-std", "-txt",
-            "-tex", cwd=str(tmp_path))
+            "-tex", "-php", cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
     assert "Searching for a set of 5 patterns with length 32" in out
@@ -88,6 +88,12 @@ def test_smart_report_lines(tmp_path):
     assert len(kernels) == 16 and kernels[0].split() == ["HOR", "hor_scan"] and kernels[2].split() == ["KMP", "kmp_runs"]
     html = list((tmp_path / "results").glob("EXP*/rand128.html"))[0].read_text()
     assert html.startswith("<!DOCTYPE html>") and html.count("<tr><td class=\"algo\">") == 16 and "class=\"best\"" in html
+    assert html.count("<svg ") == 2 and html.count("<polyline ") == 32  # the two charts: a line per algorithm each
+    php = list((tmp_path / "results").glob("EXP*/rand128.php"))[0].read_text()  # outputPHP's array (output.h:49-113)
+    assert php.startswith("<?\n$rand128 = array(\n\t\"PATT\" => array(\"32\", ),") and php.endswith(");\n?>")
+    assert re.search(r'"HOR" => array\("\d+\.\d{4}", \),', php) and '"KMP.best" => array(' in php and '"BNDML.std" => array(' in php
+    index = list((tmp_path / "results").glob("EXP*/index.html"))[0].read_text()  # outputINDEX (output.h:706-741)
+    assert '<a href="rand128.html">Experimental results on rand128</a>' in index
     tex = list((tmp_path / "results").glob("EXP*/rand128.tex"))[0].read_text()
     assert tex.startswith("\\begin{tabular}{|l|l|}") and "\\textsc{HOR} & " in tex and tex.endswith("\\end{tabular}")
     # -simple: the reference's own example (SURVEY.md §5 hazard 3 segfaults EPSM there)
