@@ -29,12 +29,17 @@ family (the KMP automaton when the timed plans run on the packed matcher, the
 packed matcher otherwise) for all K patterns and against the real reference
 build / the CPU oracle for the cpu_baseline sample.  A mismatch aborts the run.
 
-At N = 1 the line also carries "sweep": every cell of BASELINE config 2
-(HOR/BM/KMP/SO/BNDM/EPSM x m in {4,8,32,256} on the 1 GiB rand128 text) and of
-config 3 (SO, BNDM x sigma in {2,4} x m in {2..64} on 1 GiB), each timed with HIP
-events over >= 12 launches, with the kernel that ran, its fraction of the 8 TB/s
-HBM peak and a count check; cells whose plans were rerouted to another kernel
-get a second entry on the algorithm's own kernel (smartgpu_tune(0,1)).
+At N = 1 a per-cell sweep follows: every cell of BASELINE config 2
+(HOR/BM/KMP/SO/BNDM/EPSM x m in {4,8,32,256} on the 1 GiB rand128 text), of
+config 3 (SO, BNDM x sigma in {2,4} x m in {2..64} on 1 GiB) and of configs 4 and
+5 at 1 GiB, each timed with HIP events over >= 12 launches, with the kernel that
+ran, its fraction of the 8 TB/s HBM peak and a count check; cells whose plans
+were rerouted to another kernel are measured again on the algorithm's own kernel
+(smartgpu_tune(0,1)).  The CELLS go to a file (--sweep-out, default
+bench_sweep.json next to this script) — as the reference prints one summary line
+per algorithm and keeps the details in files (src/smart.c:347-378) — and the one
+JSON line on stdout carries only their summary ("min_frac", "own_kernel_min"):
+the line stays under 4 KB (compact_line), the driver keeps 8 KB of stdout.
 """
 import argparse
 import collections
@@ -106,6 +111,9 @@ def launch_ranks(n):
 
 
 def main():
+    # dmabuf IPC only on this pool: RCCL between ranks needs it, and the driver's torchrun starts the ranks
+    # without going through launch_ranks() — so every entry sets it, before torch or HIP is loaded
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -119,7 +127,9 @@ def main():
     ap.add_argument("--corpus", default="rand", help="rand (counter-based rand<sigma>) or english "
                     "(tests/golden/english_bible_world192.txt.xz tiled to --gib per GPU, BASELINE config 4)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-sweep", action="store_true", help="skip the per-cell sweep of configs 2 and 3")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the per-cell sweep of configs 2 to 5")
+    ap.add_argument("--sweep-out", default=os.path.join(ROOT, "bench_sweep.json"),
+                    help="file the sweep's cells are written to (the stdout line carries their summary only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (needs --backend gloo); the numbers mean nothing")
@@ -390,14 +400,66 @@ def main():
                                % (K, "/".join(sorted(set(others))), " and the CPU sample" if cpu else ""),
         }
         if sweep is not None:
-            out["sweep"] = sweep["cells"]
             out["min_frac"] = sweep["min_frac"]
-            out["sweep_note"] = sweep["note"]
-        print(json.dumps(out))
+            out["own_kernel_min"] = sweep["own_kernel_min"]
+            out["sweep_cells"] = len(sweep["cells"])
+            try:
+                with open(args.sweep_out, "w") as f:
+                    json.dump({"headline": out, "note": sweep["note"], "cells": sweep["cells"]}, f)
+                out["sweep_file"] = os.path.relpath(args.sweep_out, ROOT)
+            except OSError as e:   # a read-only checkout: the summary is in the line all the same
+                out["sweep_file"] = "not written: %s" % e
+        print(compact_line(out), flush=True)
 
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+LINE_LIMIT = 4096   # bytes; the driver keeps the last 8 KB of stdout (BENCH_r02.json: a 59 KB line, parsed: null)
+
+
+def compact_line(out, limit=LINE_LIMIT):
+    """The ONE stdout line: json of `out`, with the optional detail dropped (most dispensable first)
+    until it fits `limit` bytes.  The contract's keys, roofline's contract fields and cpu_baseline
+    are never dropped."""
+    out = json.loads(json.dumps(out))  # deep copy
+    drops = [("roofline", "kernel_ms_per_pattern"), ("roofline", "traffic_source"), ("config", "prewarm"),
+             ("config", "corpus"), ("config", "sharding"), ("cpu_baseline", "all_cores"), ("own_kernel_min",),
+             ("roofline", "kernels_of_the_timed_plans"), ("counts_verified",), ("min_frac",)]
+    line = json.dumps(out, separators=(",", ":"))
+    for path in drops:
+        if len(line) <= limit:
+            break
+        d = out
+        for k in path[:-1]:
+            d = d.get(k) or {}
+        d.pop(path[-1], None)
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) > limit:
+        raise SystemExit("bench line is %d bytes (> %d) even without its optional detail" % (len(line), limit))
+    return line
+
+
+# the configurations of BASELINE.json that NAME an algorithm (config 2: HOR; 3: SO, BNDM; 4: BM; 5: HOR BM KMP SO EPSM)
+NAMED_IN = {"hor": (5,), "bm": (4, 5), "kmp": (5,), "so": (3, 5), "bndm": (3,), "epsm": (5,)}
+
+
+def own_kernel_summary(cells):
+    """Per algorithm: the worst cell measured ON THE ALGORITHM'S OWN KERNEL (a cell the plan did not
+    reroute, or the cell's second entry under smartgpu_tune(0,1)) on rand128 m in {4..256} and on
+    each configuration that names the algorithm: [frac, "sigma/m"]."""
+    out = {}
+    for algo, own in OWN_KERNEL.items():
+        mine = [c for c in cells if c["algo"] == algo and c["kernel"] == own and "kernels" not in c]
+        entry = {}
+        for label, sel in [("rand128", lambda c: c["config"] == 2)] + [("config%d" % k, (lambda c, k=k: c["config"] == k)) for k in NAMED_IN[algo]]:
+            got = [c for c in mine if sel(c)]
+            if got:
+                w = min(got, key=lambda c: c["frac"])
+                entry[label] = [w["frac"], "%s/m%d" % (w["sigma"], w["m"])]
+        out[algo] = entry
+    return out
 
 
 def run_sweep(text128, device):
@@ -417,6 +479,7 @@ def run_sweep(text128, device):
     J, REPS = 3, 4
     cells = []
     ref_counts = {}
+    checked_by = collections.Counter()
 
     def time_cell(config, text, sigma, algo, m, pats, own):
         if own:
@@ -436,14 +499,17 @@ def run_sweep(text128, device):
         finally:
             if own:
                 engine.tune(0, 0)
-        # the reference count: a kernel of another family (the automaton for packed plans, else the packed matcher)
+        # the reference count: a kernel of ANOTHER family than the one that produced the count — the first of the
+        # packed matcher, the KMP automaton and Shift-Or whose plan for THIS pattern (plan's choice, no tune) launches a
+        # different kernel (on sigma 2/4 EPSM's own plan counts on so_runs: comparing so_runs with itself checks nothing)
         ok = True
         for j, (p, pl) in enumerate(zip(pats, plans)):
-            fam = "kmp" if pl.kernel_name == "packed_scan" else "epsm"
+            fam = next(f for f in ("epsm", "kmp", "so") if engine.kernel_for(f, p) != pl.kernel_name)
             key = (sigma, m, j, fam)
             if key not in ref_counts:
                 ref_counts[key] = smart_amd.search(fam, p, text)[0]
             ok = ok and counts[j] == ref_counts[key] and counts[j] >= 1
+            checked_by[engine.kernel_for(fam, p)] += 1
         for pl in plans:
             pl.free()
         kernel = kernels.most_common(1)[0][0]
@@ -496,7 +562,7 @@ def run_sweep(text128, device):
         raise SystemExit("SWEEP COUNT MISMATCH: %s" % bad)
     north = [c["frac"] for c in cells if c["config"] == 2 and not c.get("own_kernel")]
     plan = lambda k: [c["frac"] for c in cells if c["config"] == k and not c.get("own_kernel")]  # noqa: E731
-    return {"cells": cells,
+    return {"cells": cells, "own_kernel_min": own_kernel_summary(cells),
             "min_frac": {"rand128_m4to256_plan_choice": min(north),
                          "config3_plan_choice": min(plan(3)), "config4_english_plan_choice": min(plan(4)),
                          "config5_plan_choice": min(plan(5)),
@@ -506,7 +572,9 @@ def run_sweep(text128, device):
             "note": "config = BASELINE.json configuration the cell belongs to (4: the English unit tiled to 1 GiB, 5: one 1 GiB "
                     "shard per alphabet; their 4 GiB sizes: profiles/ sweeps, tests/test_configs_gpu.py); "
                     "1 GiB per cell; ms = HIP events over %d launches (%d patterns x %d); frac = 2^30 B / ms / 8 TB/s; "
-                    "own_kernel = measured again with smartgpu_tune(0,1) because the plan rerouted the pattern" % (J * REPS, J, REPS)}
+                    "own_kernel = measured again with smartgpu_tune(0,1) because the plan rerouted the pattern; "
+                    "count_ok = equal to the count of a kernel of another family (reference kernels used: %s)"
+                    % (J * REPS, J, REPS, dict(checked_by))}
 
 
 if __name__ == "__main__":

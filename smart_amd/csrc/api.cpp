@@ -6,6 +6,7 @@
 #include "../../include/smartgpu.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types, enums and prototypes only: the library itself is dlopen'ed on first use
 
 #include <dlfcn.h>
 
@@ -1093,17 +1094,22 @@ int smartgpu_bndml_search(const unsigned char* P, int m, const unsigned char* T,
 namespace {
 
 // RCCL is loaded on first use (dlopen), so the library itself has no link-time
-// dependency on it; only the multi-GPU reduce needs it.
+// dependency on it; only the multi-GPU reduce needs it.  Signatures, ncclUint64 and ncclSum
+// come from <rccl/rccl.h>: an ABI change there is a compile error here, not a silent miscount.
 struct Rccl {
     void* lib = nullptr;
-    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
-    int (*CommDestroy)(void* comm) = nullptr;
-    int (*AllReduce)(const void* send, void* recv, size_t count, int dtype, int op, void* comm, hipStream_t s) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
     bool load()
     {
         if (lib) return true;
+        // dmabuf IPC only on this pool (the legacy IPC mode fails with hipIpcGetMemHandle: invalid argument);
+        // RCCL reads it when it initialises, which is after this point
+        setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
         lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!lib) { set_error("cannot load librccl.so: %s", dlerror()); return false; }
@@ -1112,7 +1118,8 @@ struct Rccl {
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
         GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
         GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
-        if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd) {
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!CommInitAll || !CommDestroy || !AllReduce || !GroupStart || !GroupEnd || !GetErrorString) {
             set_error("librccl.so lacks an expected symbol");
             return false;
         }
@@ -1120,7 +1127,6 @@ struct Rccl {
     }
 };
 Rccl g_rccl;
-constexpr int kNcclUint64 = 5, kNcclSum = 0;  // rccl.h: ncclUint64, ncclSum
 
 }  // namespace
 
@@ -1129,7 +1135,7 @@ struct smartgpu_mtext {
     std::vector<int> devices;
     std::vector<smartgpu_text*> shards;   // shard g = bytes [begin[g], begin[g+1] + overlap)
     std::vector<uint64_t> begin;          // k+1 entries, start-position ownership
-    std::vector<void*> comms;             // RCCL communicators, created on first RCCL reduce
+    std::vector<ncclComm_t> comms;        // RCCL communicators, created on first RCCL reduce
 };
 
 namespace {
@@ -1189,7 +1195,7 @@ void smartgpu_mtext_free(smartgpu_mtext* t)
 {
     if (!t) return;
     for (smartgpu_text* s : t->shards) smartgpu_text_free(s);
-    for (void* c : t->comms)
+    for (ncclComm_t c : t->comms)
         if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
     delete t;
 }
@@ -1219,8 +1225,9 @@ int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint
     if (reduce == SMARTGPU_REDUCE_RCCL && text->comms.empty()) {
         if (!g_rccl.load()) return SMARTGPU_ERR_HIP;
         text->comms.assign(k, nullptr);
-        if (g_rccl.CommInitAll(text->comms.data(), k, text->devices.data()) != 0) {
-            set_error("ncclCommInitAll failed (devices must be distinct)");
+        const ncclResult_t st = g_rccl.CommInitAll(text->comms.data(), k, text->devices.data());
+        if (st != ncclSuccess) {
+            set_error("ncclCommInitAll over %d devices failed: %s (devices must be distinct)", k, g_rccl.GetErrorString(st));
             text->comms.clear();
             return SMARTGPU_ERR_HIP;
         }
@@ -1244,10 +1251,12 @@ int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint
         for (int g = 0; g < k && rc == SMARTGPU_OK; ++g) rc = launch_shard(g);
         if (rc != SMARTGPU_OK) return rc;
         // ONE collective for the whole pattern set: the K counts of every device, summed in place
-        g_rccl.GroupStart();
-        for (int g = 0; g < k; ++g)
-            g_rccl.AllReduce(ctx[g]->batch_counts, ctx[g]->batch_counts, K, kNcclUint64, kNcclSum, text->comms[g], ctx[g]->stream);
-        if (g_rccl.GroupEnd() != 0) { set_error("RCCL all-reduce failed"); return SMARTGPU_ERR_HIP; }
+        ncclResult_t st = g_rccl.GroupStart();
+        for (int g = 0; g < k && st == ncclSuccess; ++g)
+            st = g_rccl.AllReduce(ctx[g]->batch_counts, ctx[g]->batch_counts, K, ncclUint64, ncclSum, text->comms[g], ctx[g]->stream);
+        const ncclResult_t end = g_rccl.GroupEnd();
+        if (st == ncclSuccess) st = end;
+        if (st != ncclSuccess) { set_error("RCCL all-reduce of %u counts over %d devices failed: %s", K, k, g_rccl.GetErrorString(st)); return SMARTGPU_ERR_HIP; }
         HIP_TRY(hipSetDevice(text->devices[0]), return SMARTGPU_ERR_HIP);
         HIP_TRY(hipMemcpyAsync(ctx[0]->pinned_counts, ctx[0]->batch_counts, static_cast<size_t>(K) * 8, hipMemcpyDeviceToHost, ctx[0]->stream),
                 return SMARTGPU_ERR_HIP);

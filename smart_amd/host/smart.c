@@ -15,8 +15,10 @@
  * as inline SVG — the reference's pages load the RGraph scripts of its results/ directory,
  * which are not part of this project — and results/<code>/index.html linking the pages
  * (outputINDEX, output.h:706-741).
- * Additions: -algo LIST, -data DIR, -gpu D, device-generated rand corpora when the
- * data directory has none, a GB/s column (stdout) and <GBS> element (XML).
+ * Additions: -algo LIST, -data DIR, -gpu D, -gpus K, device-generated rand corpora when the
+ * data directory has none; every report carries GB/s of text scanned, its share of the HBM-read
+ * roofline (8 TB/s per GPU x the GPUs the text is sharded over) and the number of GPUs: columns of
+ * the stdout line, <corpus>.roofline.txt beside the TXT table, <GPUS>/<GBS>/<ROOFLINE> in the XML.
  *
  * Build: make -C smart_amd/host   (gcc, links ../csrc/libsmartgpu.so)
  */
@@ -35,6 +37,7 @@
 #define MAX_LENGTHS 17
 #define MAX_CORPORA 15
 #define MAX_RUNS 5000 /* -pset upper bound (smart.c:183 has STDTIME[5000]) */
+#define HBM_PEAK_GBS 8000.0 /* MI355X HBM3E read peak per GPU: the roofline of a byte scan */
 
 /* pattern-length sets (reference: src/sets.h:23-25) */
 static const int LEN_VERY_SHORT[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 0};
@@ -46,6 +49,8 @@ static const char *CORPUS[MAX_CORPORA] = {"rand2", "rand4", "rand8", "rand16", "
                                           "rand250", "italianTexts", "englishTexts", "frenchTexts",
                                           "chineseTexts", "midimusic", "genome", "protein"};
 static const int CORPUS_SIGMA[MAX_CORPORA] = {2, 4, 8, 16, 32, 64, 128, 250, 128, 128, 128, 128, 128, 64, 64};
+
+#define BATCH 512 /* patterns per smartgpu_search_batch64 call (the default -pset in one): the -tb limit and an ERROR are looked at between calls */
 
 /* per-search status, as the reference harness records it (smart.c:143-145,330-343) */
 enum { ST_OK = 1, ST_ERROR = 0, ST_NA = -1, ST_OUT = -2 };
@@ -59,6 +64,8 @@ struct options {
     int limit_ms;      /* -tb (smart.c:424: 300 ms) */
     int device;
     int gpus;          /* -gpus k: shard the text over k GPUs of this process, RCCL sum of the counts */
+    long seed;         /* -seed S: srandom(S) instead of the reference's srand(time(NULL)) (smart.c:432): repeatable pattern sets */
+    int reduce;        /* SMARTGPU_REDUCE_RCCL, or _HOST when the environment says SMARTGPU_REDUCE_HOST=1 (rehearsal) */
     const char *data_dir;
     char text_arg[256];
     char simple_p[128], simple_t[1100];
@@ -81,6 +88,9 @@ static void usage(void)
     printf("\t-tb L         give up on an algorithm when one search exceeds L ms (default 300)\n");
     printf("\t-dif          also print the best and the worst time\n");
     printf("\t-std          also print the standard deviation\n");
+    printf("\t              (a pattern set is searched in calls of up to %d patterns; on texts up to 32 MiB the\n", BATCH);
+    printf("\t              patterns of a call that share a kernel share ONE grid, so best, worst and std then\n");
+    printf("\t              describe the spread between such groups, not between single patterns)\n");
     printf("\t-txt          write the result table as results/<code>/<corpus>.txt\n");
     printf("\t-tex          write it as a LaTeX tabular too\n");
     printf("\t-php          write it as a PHP array (results/<code>/<corpus>.php) too\n");
@@ -90,7 +100,11 @@ static void usage(void)
     printf("\t              source/algorithms.h when that file exists)\n");
     printf("\t-data DIR     directory holding <corpus>/index.txt (default \"data\")\n");
     printf("\t-gpu D        device ordinal (default 0)\n");
-    printf("\t-gpus K       shard the text by byte offset over GPUs 0..K-1 (RCCL sum of the counts)\n");
+    printf("\t-gpus K       shard the text by byte offset over GPUs 0..K-1 (RCCL sum of the counts);\n");
+    printf("\t              with SMARTGPU_REDUCE_HOST=1 in the environment the counts are added on the host and\n");
+    printf("\t              K may exceed the visible GPUs (shard g on GPU g mod visible): a rehearsal of the\n");
+    printf("\t              sharded path on a smaller box, its times mean nothing\n");
+    printf("\t-seed S       draw the patterns from srandom(S) (default: the time, as the reference does)\n");
     printf("\t-h            this help\n\n");
 }
 
@@ -188,9 +202,7 @@ static void top_edge(void)
     printf("\n");
 }
 
-struct cell { double mean, pre, best, worst, std, gbs; int status; char kernel[24]; };
-
-#define BATCH 512 /* patterns per smartgpu_search_batch64 call (the default -pset in one): the -tb limit and an ERROR are looked at between calls */
+struct cell { double mean, pre, best, worst, std, gbs, roof; int status; char kernel[24]; }; /* roof: gbs / (GPUs x 8 TB/s) */
 
 /* One corpus: every pattern length x every algorithm x `runs` patterns
  * (reference: run_setting, src/smart.c:178-402). */
@@ -264,7 +276,7 @@ static void run_corpus(const struct options *o, const char *corpus, const unsign
                 fflush(stdout);
                 double batch_ms = 0;
                 int rc = mtext ? smartgpu_msearch_batch64(algo, (const uint8_t *const *)(pats + done), (uint32_t)m, (uint32_t)kb, mtext,
-                                                          SMARTGPU_REDUCE_RCCL, bcount, bpre, &batch_ms)
+                                                          o->reduce, bcount, bpre, &batch_ms)
                                : smartgpu_search_batch64(algo, (const uint8_t *const *)(pats + done), (uint32_t)m, (uint32_t)kb, text, 0,
                                                          (uint64_t)n, bcount, bpre, brun, &batch_ms);
                 double dev_sum = 0;
@@ -295,6 +307,7 @@ static void run_corpus(const struct options *o, const char *corpus, const unsign
                 for (int k = 1; k <= o->runs; ++k) c->std += (sample[k] - c->mean) * (sample[k] - c->mean);
                 c->std = sqrt(c->std / o->runs); /* population std, smart.c:349-351 */
                 c->gbs = c->mean > 0 ? (double)n / (c->mean * 1e-3) / 1e9 : 0;
+                c->roof = c->gbs / (HBM_PEAK_GBS * (o->gpus > 1 ? o->gpus : 1));
             }
             c->status = status;
             if (status == ST_OK) {
@@ -316,7 +329,8 @@ static void run_corpus(const struct options *o, const char *corpus, const unsign
                     for (size_t i = strlen(data); i < 15; ++i) putchar(' ');
                 }
                 if (o->occ) printf("\tocc %lld", total_occ / o->runs);
-                printf("\t%.1f GB/s\t%s", c->gbs, c->kernel);
+                /* GB/s of text scanned, its share of the HBM-read roofline of the GPUs used, #GPUs, kernel */
+                printf("\t%.1f GB/s\t%.1f%% of %d x 8 TB/s\t%s", c->gbs, 100.0 * c->roof, o->gpus > 1 ? o->gpus : 1, c->kernel);
                 printf("\n");
             } else if (status == ST_ERROR) {
                 printf("\b\b\b\b\b\b\b\b.[ERROR] \n");
@@ -377,6 +391,24 @@ static void write_txt(const struct options *o, const char *corpus, const char *c
         fprintf(fp, "\n");
     }
     fclose(fp);
+    /* and with each cell's share of the HBM-read roofline: a header line (GPUs, peak), then the table's shape */
+    snprintf(path, sizeof path, "results/%s/%s.roofline.txt", code, corpus);
+    fp = fopen(path, "w");
+    if (!fp) return;
+    fprintf(fp, "# GPUs %d\tHBM peak %.0f GB/s per GPU\tcells: %% of GPUs x peak (GB/s of text scanned)\n", o->gpus > 1 ? o->gpus : 1, HBM_PEAK_GBS);
+    for (int ia = 0; ia < o->nalgos; ++ia) {
+        char name[32];
+        upper(name, smartgpu_algo_name(o->algos[ia]));
+        fprintf(fp, "%-20s", name);
+        for (int il = 0; o->lengths[il] > 0; ++il) {
+            int m = o->lengths[il];
+            if (m < o->minlen || m > o->maxlen) continue;
+            if (table[ia][il].mean > 0) fprintf(fp, "\t%.1f%% (%.1f)", 100.0 * table[ia][il].roof, table[ia][il].gbs);
+            else fprintf(fp, "\t-");
+        }
+        fprintf(fp, "\n");
+    }
+    fclose(fp);
 }
 
 /* results/<code>/<corpus>.tex: the same table as a LaTeX tabular
@@ -417,7 +449,8 @@ static void write_tex(const struct options *o, const char *corpus, const char *c
 /* results/<code>/<corpus>.xml (reference: outputXML, src/output.h:196-247): per algorithm
  * one <DATA><SEARCH>ms</SEARCH></DATA> per length, then the best time per length.  An
  * aborted cell is a single <DATA>-</DATA> (the reference prints that AND a 0.00 block);
- * <GBS> (GB/s of text scanned) is this harness' addition. */
+ * <GPUS>, <HBMPEAK>, and per cell <GBS> (GB/s of text scanned), <ROOFLINE> (its share of GPUs x peak)
+ * and <KERNEL> are this harness' additions. */
 static void write_xml(const struct options *o, const char *corpus, const char *code,
                       struct cell table[MAX_ALGOS][MAX_LENGTHS])
 {
@@ -429,7 +462,8 @@ static void write_xml(const struct options *o, const char *corpus, const char *c
     FILE *fp = fopen(path, "w");
     if (!fp) return;
     printf("\tSaving data on %s/%s.xml\n", code, corpus);
-    fprintf(fp, "<RESULTS>\n\t<CODE>%s</CODE>\n\t<TEXT>%s</TEXT>\n", code, corpus);
+    fprintf(fp, "<RESULTS>\n\t<CODE>%s</CODE>\n\t<TEXT>%s</TEXT>\n\t<GPUS>%d</GPUS>\n\t<HBMPEAK unit=\"GB/s per GPU\">%.0f</HBMPEAK>\n", code, corpus,
+            o->gpus > 1 ? o->gpus : 1, HBM_PEAK_GBS);
     for (int ia = 0; ia < o->nalgos; ++ia) {
         char name[32];
         upper(name, smartgpu_algo_name(o->algos[ia]));
@@ -438,8 +472,8 @@ static void write_xml(const struct options *o, const char *corpus, const char *c
             if (o->lengths[il] < o->minlen || o->lengths[il] > o->maxlen) continue;
             const struct cell *c = &table[ia][il];
             if (c->mean <= 0) { fprintf(fp, "\t\t<DATA>-</DATA>\n"); continue; }
-            fprintf(fp, "\t\t<DATA>\n\t\t\t<SEARCH>%.4f</SEARCH>\n\t\t\t<GBS>%.1f</GBS>\n\t\t\t<KERNEL>%s</KERNEL>\n\t\t</DATA>\n", c->mean, c->gbs,
-                    c->kernel);
+            fprintf(fp, "\t\t<DATA>\n\t\t\t<SEARCH>%.4f</SEARCH>\n\t\t\t<GBS>%.1f</GBS>\n\t\t\t<ROOFLINE>%.4f</ROOFLINE>\n\t\t\t<KERNEL>%s</KERNEL>\n\t\t</DATA>\n",
+                    c->mean, c->gbs, c->roof, c->kernel);
         }
         fprintf(fp, "\t</ALGO>\n");
     }
@@ -620,7 +654,13 @@ int main(int argc, char **argv)
     o.lengths = LEN_LARGE;
     o.limit_ms = 300;
     o.data_dir = "data";
+    o.seed = -1;
     int custom_len[2] = {0, 0};
+    /* dmabuf IPC only on this pool: RCCL between the GPUs of -gpus K needs it, and it is read when the runtime
+     * initialises — so before the first HIP call of this process */
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+    o.reduce = SMARTGPU_REDUCE_RCCL;
+    { const char *e = getenv("SMARTGPU_REDUCE_HOST"); if (e && *e && *e != '0') o.reduce = SMARTGPU_REDUCE_HOST; }
 
     if (argc == 1) { printf("No parameter given. Use -h for help.\n\n"); return 0; }
     const char *bad = "Error in input parameters. Use -h for help.\n\n";
@@ -658,6 +698,7 @@ int main(int argc, char **argv)
         else if (!strcmp(a, "-vshort")) o.lengths = LEN_VERY_SHORT;
         else if (!strcmp(a, "-data")) { if (!has1) { printf("%s", bad); return 0; } o.data_dir = argv[++i]; }
         else if (!strcmp(a, "-gpu")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.device = atoi(argv[++i]); }
+        else if (!strcmp(a, "-seed")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.seed = atol(argv[++i]); }
         else if (!strcmp(a, "-gpus")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.gpus = atoi(argv[++i]); }
         else if (!strcmp(a, "-algo")) {
             if (!has1) { printf("%s", bad); return 0; }
@@ -679,7 +720,7 @@ int main(int argc, char **argv)
         if (n > 0) o.nalgos = n;
         else for (int i = 0; i < MAX_ALGOS; ++i) o.algos[o.nalgos++] = i;
     }
-    if (o.gpus > smartgpu_device_count()) {
+    if (o.gpus > smartgpu_device_count() && o.reduce != SMARTGPU_REDUCE_HOST) {
         fprintf(stderr, "smart: -gpus %d but only %d GPU(s) visible\n", o.gpus, smartgpu_device_count());
         return 1;
     }
@@ -687,7 +728,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "smart: no usable GPU %d: %s\n", o.device, smartgpu_last_error());
         return 1;
     }
-    srandom((unsigned)time(NULL));
+    srandom(o.seed >= 0 ? (unsigned)o.seed : (unsigned)time(NULL));
     char code[64];
     snprintf(code, sizeof code, "EXP%d", (int)time(NULL));
     static struct cell table[MAX_ALGOS][MAX_LENGTHS];
@@ -708,8 +749,8 @@ int main(int argc, char **argv)
     }
 
     /* corpus list: "all" or A-B-C (smart.c:597-667, split_filelsit function.h:112-129) */
-    const char *names[MAX_CORPORA];
-    int ncorp = 0;
+    const char *names[MAX_CORPORA], *processed[MAX_CORPORA];
+    int ncorp = 0, nproc = 0;
     char list[256];
     snprintf(list, sizeof list, "%s", o.text_arg);
     if (!strcmp(list, "all")) {
@@ -743,9 +784,16 @@ int main(int argc, char **argv)
         if (!text) { fprintf(stderr, "smart: %s\n", smartgpu_last_error()); continue; }
         smartgpu_mtext *mtext = NULL;
         if (o.gpus > 1) {  /* the same bytes, sharded over GPUs 0..gpus-1 */
-            mtext = smartgpu_mtext_upload(T, (uint64_t)n, o.gpus, NULL);
+            int devs[64], *devlist = NULL;
+            if (o.reduce == SMARTGPU_REDUCE_HOST && o.gpus <= 64) {  /* rehearsal: shard g on GPU g mod visible */
+                const int vis = smartgpu_device_count();
+                for (int g = 0; g < o.gpus; ++g) devs[g] = g % vis;
+                devlist = devs;
+            }
+            mtext = smartgpu_mtext_upload(T, (uint64_t)n, o.gpus, devlist);
             if (!mtext) { fprintf(stderr, "smart: %s\n", smartgpu_last_error()); smartgpu_text_free(text); continue; }
-            printf("\tText sharded over %d GPUs (%ld bytes each, %d bytes overlap)\n", o.gpus, n / o.gpus, SMARTGPU_XSIZE - 1);
+            printf("\tText sharded over %d GPUs (%ld bytes each, %d bytes overlap), counts summed %s\n", o.gpus, n / o.gpus, SMARTGPU_XSIZE - 1,
+                   o.reduce == SMARTGPU_REDUCE_HOST ? "on the host (SMARTGPU_REDUCE_HOST: rehearsal)" : "with one RCCL all-reduce");
         }
         alphabet_report(T, n);
         printf("\tText buffer of dimension %ld byte\n", n);
@@ -762,8 +810,9 @@ int main(int argc, char **argv)
         if (o.tex) write_tex(&o, corpus, code, table);
         if (o.php) write_php(&o, corpus, code, table);
         smartgpu_text_free(text);
+        processed[nproc++] = corpus;
     }
-    write_index(code, names, ncorp); /* smart.c:635,670 */
+    write_index(code, processed, nproc); /* smart.c:635,670; only the corpora that have a page */
     free(T);
     return 0;
 }

@@ -5,6 +5,8 @@ import glob
 import json
 import os
 
+import pytest
+
 from conftest import ROOT
 
 import bench
@@ -34,6 +36,44 @@ def test_committed_bench_lines_keep_the_contract():
         assert 0.9 < d["value"] / (d["n_gpus"] * r["achieved"]) <= 1.0001
         c = d["cpu_baseline"]
         assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["unit"] == "GB/s" and c["value"] > 0 and c["sample"]
+
+
+def test_bench_lines_fit_the_drivers_stdout_tail():
+    """The driver keeps 8 KB of stdout: round 2's line carried its 433 sweep cells (59 KB) and was cut off
+    (BENCH_r02.json: parsed null).  From round 3 on a committed line is at most 4 KB and the cells live in a file."""
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*_bench_default.json")))
+             if int(os.path.basename(os.path.dirname(f))[1:]) >= 3]
+    for f in files:
+        line = open(f).read().strip()
+        assert len(line) <= bench.LINE_LIMIT, (f, len(line))
+        d = json.loads(line)
+        assert "sweep" not in d and isinstance(d.get("min_frac"), dict) and len(d.get("own_kernel_min", {})) <= 12
+
+
+def test_compact_line_keeps_the_contract_under_4k():
+    cells = [{"config": c, "algo": a, "m": m, "sigma": s, "kernel": bench.OWN_KERNEL[a] if own else "so_runs", "ms": 0.2,
+              "frac": 0.5 + 0.001 * m ** 0.5, "count_ok": True, **({"own_kernel": True} if own else {})}
+             for c, s in ((2, 128), (3, 4), (3, 2), (4, "english"), (5, 2), (5, 32), (5, 256))
+             for a in bench.OWN_KERNEL for m in (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096) for own in (False, True)]
+    own = bench.own_kernel_summary(cells)
+    assert set(own) == set(bench.OWN_KERNEL) and own["bm"].keys() == {"rand128", "config4", "config5"}
+    assert own["bndm"]["config3"][1] in ("4/m2", "2/m2")
+    out = {"metric": "x", "value": 1.0, "unit": "GB/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 0.1,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": "w", "corpus": "c" * 300, "prewarm": "p" * 300, "sharding": "s" * 300},
+           "roofline": {"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1, "traffic": None,
+                        "traffic_source": "t" * 900, "kernel_ms_per_pattern": {"note": "n" * 900}},
+           "cpu_baseline": {"value": 1.0, "unit": "GB/s", "cores": 1, "kind": "reference", "sample": "s", "all_cores": {"x": "y" * 900}},
+           "counts_verified": "v" * 300, "min_frac": {"a": 0.5}, "own_kernel_min": own}
+    line = bench.compact_line(out)
+    assert len(line) <= bench.LINE_LIMIT and "\n" not in line
+    d = json.loads(line)
+    for k, t in REQUIRED.items():
+        assert isinstance(d.get(k), t), k
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(d["roofline"]) and "workload" in d["config"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
+    small = dict(out, config={"workload": "w"})
+    assert json.loads(bench.compact_line(small)) == json.loads(json.dumps(small)) or len(json.dumps(small)) > bench.LINE_LIMIT
 
 
 def test_latest_bench_line_agrees_with_its_rocprof_summary():
@@ -94,3 +134,25 @@ def test_plain_multi_gpu_invocation_launches_its_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
                          env=env2, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stderr + bad.stdout)
+
+
+@pytest.mark.gpu
+def test_two_ranks_rehearsed_on_one_gpu():
+    """bench.py's multi-rank code on a one-GPU box: two gloo ranks share GPU 0, each holds its shard of a 2 x 64 MiB
+    text with the (m-1)-byte overlap, the counts are summed with one all-reduce.  The numbers mean nothing; the line,
+    the rank plumbing (torch.distributed.run on 127.0.0.1, started by bench.py itself) and the counts are checked —
+    bench.py aborts on any count that differs from a kernel of another family."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                          "--steps", "5", "--warmup", "2", "--gib", "0.0625", "--no-sweep", "--no-cpu"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) <= bench.LINE_LIMIT  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["ranks"] == 2 and "gloo, rehearsal" in d["config"]["sharding"]
+    assert d["config"]["text_bytes_per_gpu"] == (1 << 26) + 31  # rank 0's shard: its starts plus m-1 bytes of the next
+    assert "all 5 counts equal" in d["counts_verified"] and d["roofline"]["bytes_per_launch"] == (1 << 26) + 31

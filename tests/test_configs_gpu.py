@@ -178,3 +178,30 @@ def test_config4_english_tiled_to_4gib(oracle):
     finally:
         engine.tune(0, 0)
     text.free()
+
+
+@pytest.mark.parametrize("config,sigma,algo,m", [(2, 128, "hor", 32), (3, 4, "so", 16), (5, 2, "kmp", 8), (3, 2, "bndm", 32),
+                                                 (5, 256, "bm", 512), (4, "english", "bm", 128)])
+def test_whole_text_against_the_cpu_at_1gib(oracle, config, sigma, algo, m):
+    """One pattern per configuration over the WHOLE 1 GiB text on both sides: the GPU count (the plan's kernel and
+    the algorithm's own) against the CPU restatement of the same algorithm run over all of the text (split by core
+    with an (m-1)-byte overlap).  Full-size parity does not rest on slices and kernel agreement alone."""
+    import os
+    n = 1 << 30
+    if sigma == "english":
+        from smart_amd import corpus
+        unit = corpus.english_unit()
+        text = Text.upload_tiled(unit, n)
+        P = unit[12345:12345 + m].copy()
+    else:
+        text = Text.generate(SEED2, sigma, n)
+        P = text.pattern(oracle.splitmix64(0x0A77E2 + m) % (n - m), m)
+    T = text.read(0, n)
+    want = oracle.search(algo, P, T, threads=os.cpu_count() or 1)
+    assert want >= 1
+    got = both_routings(lambda: smart_amd.search(algo, P, text)[0])
+    assert got == [want, want], (config, sigma, algo, m, got, want)
+    # the other end of the contract: truth is brute force (bf.c:25-39)
+    assert oracle.search("bf", P, T, threads=os.cpu_count() or 1) == want
+    del T
+    text.free()

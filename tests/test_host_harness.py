@@ -16,9 +16,9 @@ def built():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "smart_amd", "host")])
 
 
-def run(*args, cwd=None):
+def run(*args, cwd=None, env=None):
     return subprocess.run([os.path.join(BIN, args[0])] + list(args[1:]), capture_output=True, text=True,
-                          cwd=cwd or ROOT, timeout=600)
+                          cwd=cwd or ROOT, timeout=600, env=dict(os.environ, **env) if env else None)
 
 
 def test_smart_argument_errors_match_reference_messages():
@@ -78,12 +78,19 @@ def test_smart_report_lines(tmp_path):
         line = [ln for ln in out.splitlines() if re.search(r"\] %s \." % name, ln)]
         assert line and "[OK]" in line[0] and "occ 1" in line[0] and "GB/s" in line[0], (name, out)
         assert re.search(r"\d+\.\d\d+ \+ \d+\.\d\d+ ms", line[0])  # %.2f as the reference above 1 ms, %.4f below
-        assert re.search(r"GB/s\t(hor_scan|bm_scan|kmp_runs|so_runs|bndm_scan|packed_scan|hor_scan_bp|bndml_scan)$", line[0]), line[0]  # the kernel that ran
+        # GB/s, its share of the HBM-read roofline, the GPUs, the kernel that ran (SURVEY.md §5 metrics row)
+        assert re.search(r"\d+\.\d GB/s\t\d+\.\d% of 1 x 8 TB/s\t(hor_scan|bm_scan|kmp_runs|so_runs|bndm_scan|packed_scan|hor_scan_bp|bndml_scan)$", line[0]), line[0]
     table = list((tmp_path / "results").glob("EXP*/rand128.txt"))
     assert table and table[0].read_text().startswith("HOR")
     xml = list((tmp_path / "results").glob("EXP*/rand128.xml"))[0].read_text()
     assert xml.startswith("<RESULTS>") and xml.count("<NAME>") == 16 and "<SEARCH>" in xml and "<BEST>" in xml
     assert xml.count("<KERNEL>") == 16 and "<KERNEL>kmp_runs</KERNEL>" in xml
+    assert "<GPUS>1</GPUS>" in xml and "<HBMPEAK" in xml and xml.count("<ROOFLINE>") == 16
+    gbs, roof = float(re.search(r"<GBS>([\d.]+)</GBS>", xml).group(1)), float(re.search(r"<ROOFLINE>([\d.]+)</ROOFLINE>", xml).group(1))
+    assert abs(roof - gbs / 8000.0) < 2e-4
+    roofs = list((tmp_path / "results").glob("EXP*/rand128.roofline.txt"))[0].read_text().splitlines()
+    assert roofs[0].startswith("# GPUs 1\tHBM peak 8000 GB/s per GPU") and len(roofs) == 17
+    assert re.fullmatch(r"HOR +\t\d+\.\d% \(\d+\.\d\)", roofs[1]), roofs[1]
     kernels = list((tmp_path / "results").glob("EXP*/rand128.kernels.txt"))[0].read_text().splitlines()
     assert len(kernels) == 16 and kernels[0].split() == ["HOR", "hor_scan"] and kernels[2].split() == ["KMP", "kmp_runs"]
     html = list((tmp_path / "results").glob("EXP*/rand128.html"))[0].read_text()
@@ -99,3 +106,27 @@ def test_smart_report_lines(tmp_path):
     # -simple: the reference's own example (SURVEY.md §5 hazard 3 segfaults EPSM there)
     r = run("smart", "-simple", "aba", "ababababab", "-pset", "1", "-occ", cwd=str(tmp_path))
     assert r.stdout.count("occ 4") == 14, r.stdout  # hash5/hash8 do not apply to m = 3
+
+
+@pytest.mark.gpu
+def test_smart_gpus_rehearsal_on_one_box(tmp_path):
+    """`smart -gpus 3` (smart.c:140-146's call replaced by the sharded smartgpu_msearch_batch64) on a box
+    with fewer GPUs: SMARTGPU_REDUCE_HOST=1 puts shard g on GPU g mod visible and adds the counts on the
+    host.  The harness path, its shard arithmetic and its report columns run; the times mean nothing."""
+    r = run("smart", "-text", "rand4", "-plen", "2", "64", "-pset", "4", "-occ", "-seed", "7", "-gpus", "3", "-algo", "hor,bm,kmp,so,bndm,epsm",
+            cwd=str(tmp_path), env={"SMARTGPU_REDUCE_HOST": "1"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Text sharded over 3 GPUs" in r.stdout and "on the host (SMARTGPU_REDUCE_HOST: rehearsal)" in r.stdout
+    one = run("smart", "-text", "rand4", "-plen", "2", "64", "-pset", "4", "-occ", "-seed", "7", "-algo", "hor,bm,kmp,so,bndm,epsm", cwd=str(tmp_path))
+    assert one.returncode == 0, one.stdout + one.stderr
+    rows = [ln for ln in r.stdout.splitlines() if "[OK]" in ln]
+    assert len(rows) == 6 * 6 and all("% of 3 x 8 TB/s" in ln for ln in rows), r.stdout
+    assert "[ERROR]" not in r.stdout and "[--]" not in r.stdout
+    # same seed, same generated corpus: the same patterns, so the sharded run reports the very same occurrence means
+    occ = lambda out: re.findall(r"\] (\w+) \.+\[OK\].*occ (\d+)", out)  # noqa: E731
+    assert occ(r.stdout) == occ(one.stdout) and len(occ(one.stdout)) == 36
+    xml = list((tmp_path / "results").glob("EXP*/rand4.xml"))
+    assert any("<GPUS>3</GPUS>" in x.read_text() for x in xml)
+    # without the rehearsal switch more GPUs than the box has is an error, not a silent fallback
+    bad = run("smart", "-text", "rand4", "-plen", "2", "2", "-pset", "1", "-gpus", "64", cwd=str(tmp_path))
+    assert bad.returncode == 1 and "only" in bad.stderr

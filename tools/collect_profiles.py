@@ -42,6 +42,8 @@ def main():
 
     shutil.copy(os.path.join(src, "bench.json"), out("bench_default.json"))
     shutil.copy(os.path.join(src, "pytest_gpu.log"), out("pytest_gpu.log"))
+    if os.path.exists(os.path.join(src, "bench_sweep.json")):  # the cells behind the line's min_frac / own_kernel_min
+        shutil.copy(os.path.join(src, "bench_sweep.json"), out("bench_sweep.json"))
     stats = glob.glob(os.path.join(src, "prof_stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], out("bench_hor_m32_kernel_stats.csv"))

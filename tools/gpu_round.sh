@@ -3,7 +3,7 @@
 # Usage (from the repo root, on the GPU box): bash tools/gpu_round.sh <tag>
 # The session stops at the first failing step: profiles of a build that fails parity are not collected.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -12,7 +12,7 @@ step() { echo "== $1"; shift; "$@"; rc=$?; if [ $rc -ne 0 ]; then echo "FAILED r
 rm -f "$OUT/SESSION_FAILED"
 sha256sum smart_amd/csrc/kernels.hip > "$OUT/kernels_hip.sha256"   # what roofline.traffic gets bound to (collect_profiles.py)
 step "pytest -m gpu" bash -c "timeout -k 10 900 python -m pytest tests -m gpu -x -q > '$OUT/pytest_gpu.log' 2>&1; rc=\$?; tail -3 '$OUT/pytest_gpu.log'; exit \$rc"
-step "bench" bash -c "timeout -k 10 900 python bench.py > '$OUT/bench.json' 2> '$OUT/bench.err'; rc=\$?; cut -c1-600 '$OUT/bench.json'; tail -3 '$OUT/bench.err'; exit \$rc"
+step "bench" bash -c "timeout -k 10 900 python bench.py --sweep-out '$OUT/bench_sweep.json' > '$OUT/bench.json' 2> '$OUT/bench.err'; rc=\$?; cut -c1-600 '$OUT/bench.json'; tail -3 '$OUT/bench.err'; exit \$rc"
 cd /tmp
 step "rocprofv3 stats" bash -c "timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d '$OUT/prof_stats' -- python3 '$ROOT/bench.py' --steps 20 --warmup 5 --no-cpu --no-sweep > '$OUT/prof_stats.log' 2>&1"
 find "$OUT/prof_stats" -name "*kernel_stats.csv" | head -1 | xargs -r head -8
