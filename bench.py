@@ -500,16 +500,27 @@ def run_sweep(text128, device):
             if own:
                 engine.tune(0, 0)
         # the reference count: a kernel of ANOTHER family than the one that produced the count — the first of the
-        # packed matcher, the KMP automaton and Shift-Or whose plan for THIS pattern (plan's choice, no tune) launches a
-        # different kernel (on sigma 2/4 EPSM's own plan counts on so_runs: comparing so_runs with itself checks nothing)
+        # packed matcher, the KMP automaton and Shift-Or whose plan for THIS pattern launches a different kernel, under
+        # the plan's choice or, failing that, on its own kernel (on sigma 2/4 at m = 8 the plans of EPSM, KMP and SO all
+        # count on so_runs: comparing so_runs with itself checks nothing, packed_scan under tune(0,1) does)
         ok = True
         for j, (p, pl) in enumerate(zip(pats, plans)):
-            fam = next(f for f in ("epsm", "kmp", "so") if engine.kernel_for(f, p) != pl.kernel_name)
-            key = (sigma, m, j, fam)
-            if key not in ref_counts:
-                ref_counts[key] = smart_amd.search(fam, p, text)[0]
+            fam = None
+            for tuned in (0, 1):
+                engine.tune(0, tuned)
+                try:
+                    fam = next((f for f in ("epsm", "kmp", "so") if engine.kernel_for(f, p) != pl.kernel_name), None)
+                    if fam is not None:
+                        key = (sigma, m, j, fam, tuned)
+                        if key not in ref_counts:
+                            ref_counts[key] = smart_amd.search(fam, p, text)[0]
+                        checked_by[engine.kernel_for(fam, p)] += 1
+                finally:
+                    engine.tune(0, 0)
+                if fam is not None:
+                    break
+            assert fam is not None, (algo, m, sigma, pl.kernel_name)
             ok = ok and counts[j] == ref_counts[key] and counts[j] >= 1
-            checked_by[engine.kernel_for(fam, p)] += 1
         for pl in plans:
             pl.free()
         kernel = kernels.most_common(1)[0][0]

@@ -109,7 +109,9 @@ int smartgpu_search64(int algo, const uint8_t *P, uint32_t m, const smartgpu_tex
  * text range.  Preprocessing: the K tables are built on the host and placed in one arena in HBM (grown
  * when a batch needs more, never allocated per pattern); searching: K launches back to back on the
  * device's stream and ONE read-back of the K counts, so the synchronous per-call cost of
- * smartgpu_search64 (25-30 us) is paid once per pattern set.
+ * smartgpu_search64 (25-30 us) is paid once per pattern set.  On texts up to 32 MiB the patterns whose plans
+ * choose the same kernel share one grid (gridDim.y = pattern, at most 65535 per grid: a larger group is
+ * launched in slices).  K is at most 262144 (2^18) per call: SMARTGPU_ERR_ARG beyond.
  *   counts[k]   occurrences of P[k]                                   (K entries, required)
  *   pre_ms[k]   host table construction of P[k] + its share of the upload     (K entries or NULL)
  *   run_ms[k]   device time of the k-th search by HIP events — one event per pattern — (K entries or NULL:

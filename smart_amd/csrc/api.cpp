@@ -829,6 +829,7 @@ size_t batch_tail_offset(const DeviceCtx* d, uint32_t K)
     return (d->pinned_bytes - static_cast<size_t>(K) * (4 + sizeof(sg::BatchItem))) & ~size_t(63);
 }
 constexpr uint64_t kOneGridMaxText = 32ull << 20;  // pattern sets over texts up to this size run as ONE grid per kernel
+constexpr uint32_t kOneGridMaxY = 65535;            // HIP's limit on gridDim.y: patterns per grid of the one-grid form
 constexpr uint32_t kBatchMaxPatterns = 1u << 18;    // per call (argument records and launch order of a set sit in the staging buffer's tail: 9 of its 32 MB)
 
 // Build the K blobs on the host and place them in the device's arena; pre_ms[k] = host table construction of
@@ -952,7 +953,9 @@ int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, u
         // group's plan fields, which choose kernel and grid
         sg::ScanArgs first = batch_args(plans[order[i]], d, m, text, off, n, d->batch_counts);
         first.blob = d->arena;
-        HIP_TRY(sg::launch_scan_set(algo, first, dev_items + i, j - i, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
+        // gridDim.y holds at most 65535: a larger group goes as several grids over slices of its items
+        for (uint32_t lo = i; lo < j; lo += kOneGridMaxY)
+            HIP_TRY(sg::launch_scan_set(algo, first, dev_items + lo, std::min(kOneGridMaxY, j - lo), d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
         if (timed) HIP_TRY(hipEventRecord(d->batch_events[ev++], d->stream), return SMARTGPU_ERR_HIP);
         if (groups_out) groups_out->push_back({i, j - i});
         i = j;

@@ -108,6 +108,23 @@ static void usage(void)
     printf("\t-h            this help\n\n");
 }
 
+/* The pattern offsets come from a generator state of this file's own (glibc random_r, the TYPE_3 generator random()
+ * uses): libc's shared random()/rand() state is also drawn from by the GPU runtime's threads, so a seeded run
+ * (-seed) was not repeatable through srandom()/random() (smart.c:432,153 use srand(time)/random()). */
+static struct random_data draw_state;
+static char draw_buf[128];
+static void seed_draw(unsigned seed)
+{
+    memset(&draw_state, 0, sizeof draw_state);
+    initstate_r(seed, draw_buf, sizeof draw_buf, &draw_state);
+}
+static long draw(void)
+{
+    int32_t v = 0;
+    random_r(&draw_state, &v);
+    return (long)v;
+}
+
 static int is_number(const char *s)
 {
     if (!*s) return 0;
@@ -225,7 +242,7 @@ static void run_corpus(const struct options *o, const char *corpus, const unsign
             if (o->simple) {
                 memcpy(pats[i], o->simple_p, (size_t)m);
             } else {
-                long k = random() % (n - m);
+                long k = draw() % (n - m);
                 memcpy(pats[i], T + k, (size_t)m);
             }
             pats[i][m] = 0;
@@ -728,7 +745,7 @@ int main(int argc, char **argv)
         fprintf(stderr, "smart: no usable GPU %d: %s\n", o.device, smartgpu_last_error());
         return 1;
     }
-    srandom(o.seed >= 0 ? (unsigned)o.seed : (unsigned)time(NULL));
+    seed_draw(o.seed >= 0 ? (unsigned)o.seed : (unsigned)time(NULL));
     char code[64];
     snprintf(code, sizeof code, "EXP%d", (int)time(NULL));
     static struct cell table[MAX_ALGOS][MAX_LENGTHS];

@@ -123,7 +123,7 @@ def test_smart_gpus_rehearsal_on_one_box(tmp_path):
     assert len(rows) == 6 * 6 and all("% of 3 x 8 TB/s" in ln for ln in rows), r.stdout
     assert "[ERROR]" not in r.stdout and "[--]" not in r.stdout
     # same seed, same generated corpus: the same patterns, so the sharded run reports the very same occurrence means
-    occ = lambda out: re.findall(r"\] (\w+) \.+\[OK\].*occ (\d+)", out)  # noqa: E731
+    occ = lambda out: re.findall(r"\] (\w+) \..*\[OK\].*occ (\d+)", out)  # noqa: E731
     assert occ(r.stdout) == occ(one.stdout) and len(occ(one.stdout)) == 36
     xml = list((tmp_path / "results").glob("EXP*/rand4.xml"))
     assert any("<GPUS>3</GPUS>" in x.read_text() for x in xml)

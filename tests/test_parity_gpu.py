@@ -589,3 +589,24 @@ def test_runs_kernels_where_the_text_does_not_fill_the_runs(oracle):
             assert smart_amd.search(a, P, text)[0] == oracle.search("bf", P, T)
             assert smart_amd.search(a, P, text, off=0, n=n - 1)[0] == oracle.search("bf", P, T[:n - 1])
     text.free()
+
+
+def test_pattern_set_larger_than_one_grid(oracle):
+    """A set with more patterns than gridDim.y holds (65535) on a small text: the one-grid form launches the
+    group in slices; every count equals the definition.  K beyond the documented 2^18 is an argument error."""
+    n = 4096
+    T = oracle.gen_text(5, 4, 0, n)
+    text = Text.upload(T)
+    K, m = 70_001, 4
+    pats = np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(np.resize(T, K + m), m)[:K])
+    # the 256 possible patterns of 4 symbols over sigma 4, counted by definition
+    win = np.lib.stride_tricks.sliding_window_view(T, m)
+    code = lambda a: (a.astype(np.int64) * np.array([64, 16, 4, 1])).sum(axis=-1)  # noqa: E731
+    hist = np.bincount(code(win), minlength=256)
+    want = hist[code(pats)]
+    for algo in ("hor", "so", "epsm"):
+        got = smart_amd.search_batch(algo, list(pats), text, per_pattern_times=False)[0]
+        assert np.array_equal(got.astype(np.int64), want), algo
+    with pytest.raises(smart_amd.engine.SmartGpuError):
+        smart_amd.search_batch("hor", [pats[0]] * ((1 << 18) + 1), text, per_pattern_times=False)
+    text.free()
