@@ -211,6 +211,41 @@ static __device__ __forceinline__ void tile_park(uint8_t* txt, uint32_t i0, cons
     blk[(d + 3) ^ s] = v.w;
 }
 
+// Lane tiles (bm_scan, bndm_scan): the 64 text bytes a lane owns sit CONTIGUOUSLY in LDS behind a private copy of
+// the DUP = HALO - 4 bytes before them, HALO + 64 bytes per lane — an odd number of dwords, so lanes at equal
+// offsets (a streaming scan on a large alphabet moves them in lockstep) cover all 32 banks without a swizzle.
+//   * the address of T[e - k] is one subtraction from the lane's cursor (tile_at: four VALU ops per read);
+//   * bytes are contiguous, so a q-gram is ONE unaligned ds_read_b32 / _b64 (gfx950 reads LDS at any byte address),
+//     not q byte reads through the swizzle;
+//   * the price: the last DUP bytes of every segment are parked twice (16 more ds_write_b32 per tile in a quarter or
+//     half of the lanes) and a tile takes (64 + HALO) / 64 of its size in LDS.
+// Byte x (0..63) of segment s is at s * STRIDE + HALO + x; bytes [4, HALO) of a segment's region are T[seg - DUP, seg),
+// bytes [0, 4) are padding (never filled; whoever reads them ignores what they hold).
+template <int HALO>
+struct LaneTile {
+    static_assert(HALO % 16 == 4 && ((64 + HALO) / 4) % 2 == 1, "16 or 32 duplicated bytes + 4 of padding, odd dword stride");
+    static constexpr uint32_t STRIDE = 64 + HALO, DUP = HALO - 4;
+    static __host__ __device__ constexpr uint32_t bytes(uint32_t segments) { return segments * STRIDE; }
+    // park the j-th 16-byte chunk of the tile (segment j / 4, quarter j % 4); the last DUP / 16 quarters of a
+    // segment also go in front of the next one
+    static __device__ __forceinline__ void park(uint8_t* txt, uint32_t j, const uint4& v, uint32_t segments)
+    {
+        const uint32_t s = j >> 2, part = j & 3u;
+        uint32_t* d = reinterpret_cast<uint32_t*>(txt + s * STRIDE + HALO + 16u * part);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        if (part >= 4u - DUP / 16u && s + 1 < segments) {
+            uint32_t* h = reinterpret_cast<uint32_t*>(txt + (s + 1) * STRIDE + HALO + 16u * part - 64u);
+            h[0] = v.x; h[1] = v.y; h[2] = v.z; h[3] = v.w;
+        }
+    }
+    // chunk t (< DUP / 16) of the DUP bytes in front of the tile: segment 0's copy
+    static __device__ __forceinline__ void park_front(uint8_t* txt, uint32_t t, const uint4& v)
+    {
+        uint32_t* h = reinterpret_cast<uint32_t*>(txt + 4u + 16u * t);
+        h[0] = v.x; h[1] = v.y; h[2] = v.z; h[3] = v.w;
+    }
+};
+
 // ---------------------------------------------------------------------------
 // Horspool  (reference: src/algos/hor.c:26-51)
 // LDS: u16 tab[256] | pattern tail P[m-1-H..m-1] | text [tile0-H16, tile0+TB)
@@ -550,7 +585,20 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a1, uint64_t 
 
 // ---------------------------------------------------------------------------
 // Boyer-Moore  (reference: src/algos/bm.c:27-93)
-// LDS: u16 bc[256] | u16 gs[m] | pattern tail | text [tile0-H16, tile0+TB)
+// LDS: u16 bc[256] | u32 walk[H+2] | lane tile (LaneTile<kBmHalo>)
+//
+// The lane loop is ONE flat loop over (e, k) — window end, bytes of the window matched so far — in which every
+// iteration reads ONE text byte c = T[e-k], its bad-character entry bc[c] and walk[k] = (gs[m-1-k] << 9) | P[m-1-k]
+// (whose address does not depend on the text: the two reads are in flight together), and does bm.c:83-89 for i = m-1-k:
+//     c == P[m-1-k]  ->  k+1            else  ->  e += max(gs[m-1-k], bc[c] - k), k = 0
+// A fresh window is nothing special: k = 0 compares with P[m-1] and shifts by max(gs[m-1], bc[c]).  An occurrence
+// (m-1 = H: the whole window is in LDS) is the state k = H+1: walk[H+1] = (gs[0] << 9) | 0x100 never compares equal
+// and moves on by gs[0] (bm.c:86; bc[.] - m <= 0), the lane counts it on the way.
+// Round 2's loop opened a window with two folded tables and walked a surviving one in a nested loop: while one lane
+// compared, the other 63 stood still, and every level of the nest was paid in exec-mask bookkeeping — 4.9 SCALAR
+// instructions per text byte and lane next to 3.0 vector ones on English (m = 128, profiles/r03/a_pmc_bm_english.txt:
+// the CU's one scalar unit ~90 % busy).  Here a lane that compares and a lane that opens its next window run the
+// same instructions; the only branches are the loop's own and, for long patterns, one wave-uniform test.
 // ---------------------------------------------------------------------------
 template <int THREADS, int L, bool LONG>  // LONG: m-1 > back halo
 __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_first,
@@ -558,115 +606,102 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_fi
 {
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
+    using LT = LaneTile<kBmHalo>;  // H <= kHaloMax = 16 bytes back, one more for the occurrence state (read, ignored)
+    static_assert(L == 64 && kBmHalo >= kHaloMax + 1, "a lane owns one 64-byte segment of a lane tile");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t m = a.m, H = a.halo, H16 = round16(H);
-    // first[c] = shift after a mismatch on the window's LAST byte, max(gs[m-1], bc[c]), or
-    // 0x8000 when c == P[m-1]: like Horspool, a window that dies on its last byte (almost
-    // all of them on large alphabets) costs one text read and one table read
-    uint16_t* first = reinterpret_cast<uint16_t*>(smem);
-    // second[c]: the same for the byte before the last, max(gs[m-2], bc[c] - 1) or the flag: the byte is
-    // read together with the last one, so a window that dies there (nearly all that survive the last
-    // byte) costs one more table read instead of a walk step plus the gs and bc reads (78-82 % -> see
-    // DESIGN.md §8)
-    uint16_t* second = first + 256;
-    uint16_t* bc = second + 256;
-    uint16_t* gs = bc + 256;
-    uint8_t* ptail = smem + 1536 + round16(2 * (m + 1));
-    uint8_t* txt = ptail + round16(H + 1);
+    const uint32_t m = a.m, H = a.halo;
+    uint16_t* bc = reinterpret_cast<uint16_t*>(smem);
+    uint32_t* walk = reinterpret_cast<uint32_t*>(smem + 512);  // walk[k], 0 <= k <= H+1
+    constexpr uint32_t kTxt = 512 + 4 * (kHaloMax + 2 + 2);    // 592: the lane tile
+    uint8_t* txt = smem + kTxt;
 
+    // the blob: u16 first[256], second[256] (round 2's folded tables; unused here), bc[256], gs[m], safe
     const uint16_t* gtab = reinterpret_cast<const uint16_t*>(a.blob + kTableOff);
-    for (uint32_t i = threadIdx.x; i < 768 + m + 1; i += THREADS) first[i] = gtab[i];  // first, second, bc, gs[0..m-1], safe shift
-    for (uint32_t i = threadIdx.x; i <= H; i += THREADS) ptail[i] = a.blob[m - 1 - H + i];
+    for (uint32_t i = threadIdx.x; i < 256; i += THREADS) bc[i] = gtab[512 + i];
+    const uint32_t gs0 = gtab[768];       // bm.c:86: the shift after an occurrence
+    const uint32_t safe = gtab[768 + m];  // for a parked window (api.cpp build_blob)
+    for (uint32_t k = threadIdx.x; k <= H + 1; k += THREADS)
+        walk[k] = k <= H ? ((uint32_t)gtab[768 + m - 1 - k] << 9) | a.blob[m - 1 - k] : (gs0 << 9) | 0x100u;
 
     const uint64_t e_begin = a.s_begin + m - 1, e_end = a.s_end + m - 1;
     uint32_t hits = 0;
-    static_assert(TB == THREADS * 64, "prefetch registers are written out for L = 64");
-    uint4 p0, p1, p2, p3, ph;  // prefetch registers: 4 tile rows + one halo chunk
-    const bool halo_lane = threadIdx.x * 16u < H16;
+    uint4 p0, p1, p2, p3, ph;  // prefetch registers: 4 tile rows + the 16 bytes in front of the tile
     auto issue = [&](uint64_t tile0) {
         const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
         p0 = ld_stream16(src);
         p1 = ld_stream16(src + THREADS * 16);
         p2 = ld_stream16(src + THREADS * 32);
         p3 = ld_stream16(src + THREADS * 48);
-        if (halo_lane) ph = ld_stream16(src - H16);
+        if (threadIdx.x == 0) ph = ld_stream16(src - LT::DUP);
     };
     const uint64_t t_end = tile_first + ntiles;
     uint64_t t = tile_first + blockIdx.x;
     issue(t * TB);
+    const uint32_t own = kTxt + threadIdx.x * LT::STRIDE + kBmHalo;  // LDS offset of the lane's own first byte
     for (; t < t_end; t += gridDim.x) {
         const uint64_t tile0 = t * TB;
         __syncthreads();
-        {   // dword-swizzled like hor_scan's tile (tile_at)
-            const uint32_t i0 = H16 + threadIdx.x * 16u;
-            tile_park(txt, i0, p0);
-            tile_park(txt, i0 + THREADS * 16, p1);
-            tile_park(txt, i0 + THREADS * 32, p2);
-            tile_park(txt, i0 + THREADS * 48, p3);
-            if (halo_lane) tile_park(txt, threadIdx.x * 16u, ph);
-        }
+        LT::park(txt, threadIdx.x, p0, THREADS);
+        LT::park(txt, THREADS + threadIdx.x, p1, THREADS);
+        LT::park(txt, 2 * THREADS + threadIdx.x, p2, THREADS);
+        LT::park(txt, 3 * THREADS + threadIdx.x, p3, THREADS);
+        if (threadIdx.x == 0) LT::park_front(txt, 0, ph);
         __syncthreads();
         if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
+        // window ends [x0, x1) of the lane's segment are its own
+        uint32_t x0 = 0, x1 = L;
         const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
-        const uint64_t lo = seg > e_begin ? seg : e_begin;
-        const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+        if (tile0 < e_begin || tile0 + TB > e_end) {  // (uniform) a tile at either end of the range
+            const uint64_t lo = seg > e_begin ? seg : e_begin;
+            const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+            x0 = lo < hi ? (uint32_t)(lo - seg) : 0u;
+            x1 = lo < hi ? (uint32_t)(hi - seg) : 0u;
+        }
         bool parked = false;  // first candidate of this tile awaiting wave_verify
         const uint8_t* parked_at = a.text;
-        if (lo < hi) {
-            uint32_t e = (uint32_t)(lo - tile0) + H16;
-            const uint32_t ehi = (uint32_t)(hi - tile0) + H16;
-            while (e < ehi) {
-                // right-to-left comparison (bm.c:83); k = bytes matched
-                uint32_t c = txt[tile_at(e)];
-                const uint32_t c1 = txt[tile_at(e - 1)];  // m >= 2 here (launch_scan sends one-byte patterns to the packed matcher)
-                const uint32_t ent = first[c];
-                if (!(ent & 0x8000u)) {  // mismatch on the last byte: bm.c:89 with i = m-1
-                    e += ent;
-                    continue;
-                }
-                const uint32_t ent1 = second[c1];
-                if (!(ent1 & 0x8000u)) {  // ... on the byte before it: i = m-2
-                    e += ent1;
-                    continue;
-                }
-                uint32_t k = 2;
-                bool mismatch = false;
-                while (k <= H) {
-                    c = txt[tile_at(e - k)];
-                    if (c != ptail[H - k]) { mismatch = true; break; }
-                    ++k;
-                }
-                bool deferred = false;
-                if (LONG && !mismatch && k < m) {  // the halo is exhausted: the rest is in HBM
-                    const uint8_t* tp = a.text + tile0 + (e - H16);
+        uint32_t e = own + x0, k = 0;
+        const uint32_t ehi = own + x1;
+        while (e < ehi) {
+            // m >= 2 here (launch_scan sends one-byte patterns to the packed matcher)
+            const uint32_t c = smem[e - k];
+            const uint32_t wk = walk[k];
+            const int b = (int)bc[c] - (int)k;  // bmBc[c] - m + 1 + i, i = m-1-k
+            if (!LONG) hits += k > H;
+            const bool eq = c == (wk & 0x1FFu);
+            const int g = (int)(wk >> 9);
+            uint32_t adv = eq ? 0u : (uint32_t)(g > b ? g : b);  // bm.c:89
+            uint32_t nk = eq ? k + 1 : 0u;
+            if (LONG && __any(nk > H)) {  // rare, wave-uniform: the halo is exhausted, the rest is in HBM
+                if (nk > H) {
+                    const uint8_t* tp = a.text + seg + (e - own);  // the window's last byte
                     if (!parked) {
-                        // park the first candidate of the tile for wave_verify; move on by a
-                        // shift that is safe whatever the outcome (min of gs over the
-                        // positions still unchecked, computed on the host)
+                        // park the first candidate of the tile for wave_verify; move on by a shift that is safe
+                        // whatever the outcome (min of gs over the positions still unchecked, from the host)
                         parked = true;
                         parked_at = tp - (m - 1);
-                        deferred = true;
+                        adv = safe;
                     } else {
-                        while (k < m) {
-                            c = tp[-(int64_t)k];
-                            if (c != a.blob[m - 1 - k]) { mismatch = true; break; }
-                            ++k;
+                        uint32_t kk = nk, cc = 0;
+                        bool mismatch = false;
+                        while (kk < m) {
+                            cc = tp[-(int64_t)kk];
+                            if (cc != a.blob[m - 1 - kk]) { mismatch = true; break; }
+                            ++kk;
+                        }
+                        if (!mismatch) {
+                            ++hits;
+                            adv = gs0;
+                        } else {
+                            const int g2 = gtab[768 + m - 1 - kk], b2 = (int)bc[cc] - (int)kk;
+                            adv = (uint32_t)(g2 > b2 ? g2 : b2);
                         }
                     }
+                    nk = 0;
                 }
-                uint32_t shift;
-                if (deferred) {
-                    shift = gs[m];  // safe shift (see api.cpp build_blob)
-                } else if (!mismatch) {
-                    ++hits;
-                    shift = gs[0];  // bm.c:86
-                } else {
-                    const int g = gs[m - 1 - k];
-                    const int b = (int)bc[c] - (int)k;  // bmBc[c] - m + 1 + i, i = m-1-k
-                    shift = (uint32_t)(g > b ? g : b);  // bm.c:89
-                }
-                e += shift;
             }
+            e += adv;
+            k = nk;
+            // (no lane leaves the loop in the occurrence state: the step that enters it does not move e)
         }
         if (LONG) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
@@ -2013,6 +2048,7 @@ uint32_t short_pattern_max_m(int algo)
 // tile shapes (threads, bytes per lane)
 constexpr int kHorT = 256, kHorL = 64;
 constexpr int kBmT = 256, kBmL = 64;
+constexpr int kBmBusyT = 128;  // bm_scan where windows survive (English, small alphabets): two-wave workgroups, 12 per CU (launch_scan)
 constexpr int kBndmT = 256, kBndmL = 64;
 #ifdef SMARTGPU_AB
 constexpr int kSoT = 256, kSoL = 80;  // so_scan
@@ -2399,7 +2435,17 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
                 return launch_packed<SMARTGPU_BM>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
             }
             const uint32_t H = a.halo;
-            const size_t lds = 1536 + r16(2 * (m + 1)) + r16(H + 1) + ((r16(H) + (size_t)kBmT * kBmL + 63) & ~(size_t)63);  // whole 64-byte blocks (tile_at)
+            // Patterns whose symbols repeat (a.sparse == 0: natural language, small alphabets; only under tune(0,1) —
+            // the plan sends them to so_runs): every lane is busy with candidates and a workgroup waits for its slowest
+            // wave at each tile.  Two-wave workgroups, 12 per CU: English m = 4 / 8 / 32 / 128: 55 / 71 / 73 / 72 % against
+            // 51 / 68 / 70 / 73 % with 6 four-wave workgroups (7: 52 / 63 / 69 / 70 %; 14 two-wave: 52 / 64 / 66 / 69 %).
+            if (!a.sparse) {
+                const size_t lds = 512 + 4 * (kHaloMax + 2 + 2) + LaneTile<kBmHalo>::bytes(kBmBusyT);  // bc, walk, the lane tile
+                const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmBusyT * kBmL);
+                if (m - 1 > H) return launch_tiled(bm_scan<kBmBusyT, kBmL, true>, a, tr, kBmBusyT, lds, 12, num_cus, stream);
+                return launch_tiled(bm_scan<kBmBusyT, kBmL, false>, a, tr, kBmBusyT, lds, 12, num_cus, stream);
+            }
+            const size_t lds = 512 + 4 * (kHaloMax + 2 + 2) + LaneTile<kBmHalo>::bytes(kBmT);  // bc, walk, the lane tile
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmT * kBmL);
             const int wgs = tile_wgs(a, true);
             if (m - 1 > H) return launch_tiled(bm_scan<kBmT, kBmL, true>, a, tr, kBmT, lds, wgs, num_cus, stream);

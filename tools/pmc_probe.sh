@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC probe of one (algo, m, sigma): bash tools/pmc_probe.sh <tag> <algo> <m> <sigma> "<counters pass 1>" "<counters pass 2>" ...
+# PMC probe of one (algo, m, sigma): [EXTRA="--corpus english --own"] bash tools/pmc_probe.sh <tag> <algo> <m> <sigma> "<counters pass 1>" "<counters pass 2>" ...
 set -o pipefail
 TAG=$1; ALGO=$2; M=$3; SIGMA=$4; shift 4
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$TAG; mkdir -p "$OUT"
@@ -8,7 +8,7 @@ cd /tmp
 i=0
 for CTRS in "$@"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $CTRS --output-format csv -d "$OUT/pmc_${ALGO}_m${M}_s${SIGMA}_p$i" -- python3 "$ROOT/tools/sweep.py" --algos $ALGO --ms $M --sigma $SIGMA --reps 3 > "$OUT/pmc_${ALGO}_m${M}_p$i.log" 2>&1 || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --pmc $CTRS --output-format csv -d "$OUT/pmc_${ALGO}_m${M}_s${SIGMA}_p$i" -- python3 "$ROOT/tools/sweep.py" --algos $ALGO --ms $M --sigma $SIGMA --reps 3 $EXTRA > "$OUT/pmc_${ALGO}_m${M}_p$i.log" 2>&1 || echo "pass $i failed"
 done
 cd "$ROOT"
 python3 - "$OUT" <<'PY'
