@@ -201,10 +201,11 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
     // The count does not depend on the choice.
     bool repeats = false;
     bool repeats_short = false;  // 7 bytes or fewer with a symbol that occurs twice (a small alphabet, most likely)
+    uint64_t pairs = 0;          // ordered pairs of equal symbols in P: pairs / (m (m-1)) estimates P(two symbols are equal)
+    uint32_t distinct = 0;       // symbols that occur in P
     {
         uint32_t cnt[256] = {0};
-        for (uint32_t i = 0; i < m; ++i) ++cnt[P[i]];
-        uint64_t pairs = 0;
+        for (uint32_t i = 0; i < m; ++i) distinct += cnt[P[i]]++ == 0;
         for (uint32_t c = 0; c < 256; ++c) pairs += static_cast<uint64_t>(cnt[c]) * (cnt[c] > 0 ? cnt[c] - 1 : 0);
         // m < 32: too few symbols for the estimate; two equal pairs are taken as a sign (rand32, m = 16:
         // skip kernels 58-65 %, packed 76 %; on rand128 one pattern in four then goes packed, 76 % for 83 %)
@@ -319,6 +320,27 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
             const std::vector<uint32_t> B = sg::bndm_masks(P, m);
             append(B.data(), 1024);
             append_fingerprint();  // packed regime
+            if (algo != SMARTGPU_SBNDM) {
+                // bndm_scan reads q bytes of a window per iteration: the smallest q of 1, 2, 4, 8 (at most half the
+                // window, and a divisor of it) for which a window rarely outlives its first iteration — the chance that the q-gram at its
+                // end occurs in P[0..w), (w-q+1) * p^q with p = P(two symbols are equal) estimated from the pattern
+                // itself, is below 0.3.  rand128: 1; English: 2; four symbols: 4; two: 8.  Travels as the plan's halo
+                // (bndm_scan's lane tiles always hold the 32 bytes before a segment).
+                const uint32_t w = std::min<uint32_t>(m, 32);
+                double p = m > 1 ? std::max(static_cast<double>(pairs) / (static_cast<double>(m) * (m - 1)), 1.0 / 256) : 1.0;
+                // (few symbols for the estimate: a pattern in which at most half of the symbols are distinct comes from
+                // an alphabet of about that many — rand4, m = 8: the pair count says 0.05 .. 0.4, four symbols say 0.25)
+                if (distinct * 2 <= m) p = std::max(p, 1.0 / distinct);
+                uint32_t q = 1;
+                while (q < 8 && 2 * q <= std::max(w / 2, 1u)) {
+                    double survive = static_cast<double>(w - q + 1);
+                    for (uint32_t i = 0; i < q; ++i) survive *= p;
+                    if (survive < 0.3) break;
+                    q *= 2;
+                }
+                while (w % q) q /= 2;  // q | w: a window is read through in whole iterations
+                *halo = q;
+            }
             if (algo == SMARTGPU_SBNDM) {  // sbndm.c:44-55: the shift after an occurrence = period of P[0..w)
                 const uint32_t w = std::min<uint32_t>(m, 32);
                 const std::vector<int32_t> nx = sg::kmp_next(P, w);  // nx[w] = longest proper border of the prefix

@@ -709,7 +709,130 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_fi
 }
 
 // ---------------------------------------------------------------------------
-// BNDM, 32-bit words like the reference  (src/algos/bndm.c:27-111)
+// BNDM with q-grams, 32-bit words like the reference  (src/algos/bndm.c:27-111; reading q bytes of a window at
+// once is bndmq2.c / bndmq4.c:29-72's idea).  w = min(m,32); tiles are indexed by the END of the w-byte (prefix) window.
+// LDS: u32 B[256] (left-aligned: B[c] << (32-w)) | lane tile (LaneTile<kBndmHalo>)
+//
+// One flat loop over (e, k, D) — window end, bytes of the window read, the factors of P still alive — in which every
+// iteration reads the NEXT Q BYTES of the window, T[e-k-Q+1 .. e-k], with ONE unaligned LDS read, looks up their Q
+// masks and takes Q steps of bndm.c:49-58 at once (bndmq4.c:29's GRAM4):
+//     t = (D << (Q-1)) & (B[c_0] << (Q-1)) & (B[c_1] << (Q-2)) & ... & B[c_{Q-1}],   D' = t << 1
+// (Q | w: a window is read through in whole iterations).  The sign bit of t <=> the k+Q bytes read are a prefix of P —
+// all w of them: an occurrence.  D' == 0 — no factor alive, or the window read through (the masks are left-aligned: the
+// last bit leaves with the w-th step) — ends the window, and e moves by w - (k+Q) + 1: the k+Q bytes are no factor of P
+// (or all of it), the k+Q-1 after their first may be (bndmq4.c:61: i += m-q+1) — by w - (k+Q) when they are a prefix
+// of P themselves (bndm.c:54; what it remembers INSIDE a gram — a longer safe shift now and then — is not kept: the
+// masks of a gram are ANDed before anything is tested).
+// Lanes that open a window and lanes that are deep in one run the same instructions; no nested loop, no divergence
+// beyond the loop's own exit.  3Q + 14 VALU instructions and Q + 1 LDS reads per iteration.
+// Q comes from the plan (api.cpp build_blob, from the pattern's own symbol statistics): the smallest of 1, 2, 4, 8 for
+// which most windows die in their first iteration.  On a large alphabet that is 1 — one text byte, one mask, as round
+// 2's loop; English: 2; four symbols: 4; two: 8 — where a loop that reads byte by byte and tests after each walks
+// five to eight dependent LDS round trips deep into nearly every window (rand4 m = 32: 66 %, rand2: 38 %).
+// ---------------------------------------------------------------------------
+template <int THREADS, int L, bool LONG, int Q>  // LONG: m > 32, prefix hits are verified
+__global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_first,
+                                                     uint32_t ntiles, const BatchItem* __restrict__ batch)
+{
+    const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    constexpr int TB = THREADS * L;
+    using LT = LaneTile<kBndmHalo>;  // a window reaches 31 bytes back
+    static_assert(L == 64 && kBndmHalo >= 32 + 4 && (Q == 1 || Q == 2 || Q == 4 || Q == 8), "Q divides 32: no read leaves the window's 32 bytes");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m, w = m < 32 ? m : 32;
+    uint32_t* B = reinterpret_cast<uint32_t*>(smem);
+    constexpr uint32_t kTxt = 1024;
+    uint8_t* txt = smem + kTxt;
+
+    // masks left-aligned (B'[c] = B[c] << (32-w)): D << 1 then drops factors that can no longer become a prefix, instead
+    // of carrying dead bits above bit w-1 as bndm.c's 32-bit word does for m < 32 (the next AND clears them either way:
+    // same D & B, same count) — and "a prefix" is the sign bit
+    for (uint32_t i = threadIdx.x; i < 256; i += THREADS)
+        B[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] << (32 - w);
+
+    const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
+    uint32_t hits = 0;
+    uint4 p0, p1, p2, p3, ph;  // prefetch registers: 4 tile rows + (threads 0, 1) the 32 bytes in front of the tile
+    auto issue = [&](uint64_t tile0) {
+        const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
+        p0 = ld_stream16(src);
+        p1 = ld_stream16(src + THREADS * 16);
+        p2 = ld_stream16(src + THREADS * 32);
+        p3 = ld_stream16(src + THREADS * 48);
+        if (threadIdx.x < LT::DUP / 16) ph = ld_stream16(src - LT::DUP);
+    };
+    const uint64_t t_end = tile_first + ntiles;
+    uint64_t t = tile_first + blockIdx.x;
+    issue(t * TB);
+    const uint32_t own = kTxt + threadIdx.x * LT::STRIDE + kBndmHalo;  // LDS offset of the lane's own first byte
+    for (; t < t_end; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();
+        LT::park(txt, threadIdx.x, p0, THREADS);
+        LT::park(txt, THREADS + threadIdx.x, p1, THREADS);
+        LT::park(txt, 2 * THREADS + threadIdx.x, p2, THREADS);
+        LT::park(txt, 3 * THREADS + threadIdx.x, p3, THREADS);
+        if (threadIdx.x < LT::DUP / 16) LT::park_front(txt, threadIdx.x, ph);
+        __syncthreads();
+        if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
+        // window ends [x0, x1) of the lane's segment are its own
+        uint32_t x0 = 0, x1 = L;
+        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+        if (tile0 < e_begin || tile0 + TB > e_end) {  // (uniform) a tile at either end of the range
+            const uint64_t lo = seg > e_begin ? seg : e_begin;
+            const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+            x0 = lo < hi ? (uint32_t)(lo - seg) : 0u;
+            x1 = lo < hi ? (uint32_t)(hi - seg) : 0u;
+        }
+        bool parked = false;  // first candidate of this tile awaiting wave_verify
+        const uint8_t* parked_at = a.text;
+        uint32_t e = own + x0, k = 0, D = 0xFFFFFFFFu;
+        const uint32_t ehi = own + x1;
+        while (e < ehi) {
+            // the window's next Q bytes, T[e-k-Q+1 .. e-k]: byte Q-1 of X is the one bndm.c:50 reads first (right to left)
+            uint32_t xw[2] = {0u, 0u};
+            if (Q == 1) xw[0] = smem[e - k];
+            else __builtin_memcpy(xw, smem + (e - k - (Q - 1)), Q);
+            uint32_t G = 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {  // step j reads byte Q-1-j; its mask meets D after Q-1-j more shifts
+                const int i = Q - 1 - j;
+                const uint32_t c = (xw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                G &= B[c] << i;
+            }
+            const uint32_t tt = (D << (Q - 1)) & G;  // bndm.c:51, Q times
+            const uint32_t kq = k + Q;
+            const bool occ = (int32_t)tt < 0 && kq == w;  // bndm.c:55: all w bytes are read and the factor alive is P[0..w) itself
+            D = tt << 1;                                  // bndm.c:57
+            const bool done = D == 0;  // no factor alive, or the window is read through
+            if (!LONG) {
+                hits += occ;
+            } else if (__any(occ)) {  // rare, wave-uniform: the 32-byte prefix matched, verify P[32..m) (bndm.c:99-102)
+                if (occ) {
+                    const uint8_t* rest = a.text + seg + (e - own) + 1;  // = text + s + w; inside the text because s < s_end
+                    if (!parked) {
+                        parked = true;
+                        parked_at = rest;
+                    } else {
+                        hits += global_equal(rest, a.blob + w, m - w);
+                    }
+                }
+            }
+            // the window ends.  tt == 0: the kq bytes are no factor of P, the kq-1 after their first may be a prefix: move by
+            // w - (kq-1) (bndmq4.c:61); tt != 0 — its sign bit alone, or D' would not be 0 — they ARE a prefix of P: move by
+            // w - kq (bndm.c:54), by 1 after an occurrence
+            e += done ? w - kq + ((tt == 0 || kq == w) ? 1u : 0u) : 0u;
+            k = done ? 0u : kq;
+            D = done ? 0xFFFFFFFFu : D;
+        }
+        if (LONG) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
+    }
+    flush_hits(hits, a.count, smem);
+}
+
+// ---------------------------------------------------------------------------
+// Simplified BNDM (sbndm.c:28-149) on round 2's BNDM tiles — flat, dword-swizzled, a nested loop per window (bndm_scan
+// above is BNDM's kernel now; the SIMPLE = false path below is what it replaced and is not instantiated).
 // w = min(m,32); tiles are indexed by the END of the w-byte (prefix) window.
 // LDS: u32 B[256] | text [tile0-32, tile0+TB)
 // ---------------------------------------------------------------------------
@@ -718,7 +841,7 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_fi
 // w-k), an occurrence moves by the period of the (prefix of the) pattern, which the host stores
 // after the fingerprint.
 template <int THREADS, int L, bool LONG, bool SIMPLE>  // LONG: m > 32, prefix hits are verified
-__global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_first,
+__global__ __launch_bounds__(THREADS) void sbndm_scan(ScanArgs a1, uint64_t tile_first,
                                                      uint32_t ntiles, const BatchItem* __restrict__ batch)
 {
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
@@ -2050,6 +2173,7 @@ constexpr int kHorT = 256, kHorL = 64;
 constexpr int kBmT = 256, kBmL = 64;
 constexpr int kBmBusyT = 128;  // bm_scan where windows survive (English, small alphabets): two-wave workgroups, 12 per CU (launch_scan)
 constexpr int kBndmT = 256, kBndmL = 64;
+constexpr int kBndmBusyT = 128;  // bndm_scan where windows survive: two-wave workgroups (launch_scan)
 #ifdef SMARTGPU_AB
 constexpr int kSoT = 256, kSoL = 80;  // so_scan
 #endif
@@ -2092,7 +2216,7 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_m
             if (m > 32) return pk ? "packed_scan" : "bndml_scan";
             [[fallthrough]];
         case SMARTGPU_SBNDM:
-        case SMARTGPU_BNDM: return (pk || (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1)) ? "packed_scan" : "bndm_scan";
+        case SMARTGPU_BNDM: return (pk || (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1)) ? "packed_scan" : algo == SMARTGPU_SBNDM ? "sbndm_scan" : "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
     }
     return "?";
@@ -2439,7 +2563,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
             // the plan sends them to so_runs): every lane is busy with candidates and a workgroup waits for its slowest
             // wave at each tile.  Two-wave workgroups, 12 per CU: English m = 4 / 8 / 32 / 128: 55 / 71 / 73 / 72 % against
             // 51 / 68 / 70 / 73 % with 6 four-wave workgroups (7: 52 / 63 / 69 / 70 %; 14 two-wave: 52 / 64 / 66 / 69 %).
-            if (!a.sparse) {
+            if (g_tune[2] ? g_tune[2] == 2 : !a.sparse) {  // tune(2, 1 / 2): four-wave / two-wave workgroups
                 const size_t lds = 512 + 4 * (kHaloMax + 2 + 2) + LaneTile<kBmHalo>::bytes(kBmBusyT);  // bc, walk, the lane tile
                 const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmBusyT * kBmL);
                 if (m - 1 > H) return launch_tiled(bm_scan<kBmBusyT, kBmL, true>, a, tr, kBmBusyT, lds, 12, num_cus, stream);
@@ -2475,14 +2599,36 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
                 return launch_packed<SMARTGPU_BNDM>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
             }
             const uint32_t w = m < 32 ? m : 32;
-            const size_t lds = 1024 + ((32 + (size_t)kBndmT * kBndmL + 63) & ~(size_t)63);  // whole 64-byte blocks (tile_at)
-            const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
             if (algo == SMARTGPU_SBNDM) {
-                if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
-                return launch_tiled(bndm_scan<kBndmT, kBndmL, false, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
+                const size_t lds = 1024 + ((32 + (size_t)kBndmT * kBndmL + 63) & ~(size_t)63);  // whole 64-byte blocks (tile_at)
+                const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
+                if (m > 32) return launch_tiled(sbndm_scan<kBndmT, kBndmL, true, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
+                return launch_tiled(sbndm_scan<kBndmT, kBndmL, false, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
             }
-            if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
-            return launch_tiled(bndm_scan<kBndmT, kBndmL, false, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
+            // BNDM (and BNDML's m <= 32): q bytes of a window per iteration, q = a.halo from the plan (api.cpp bndm_q).
+            // Patterns whose symbols repeat (a.sparse == 0; only under tune(0,1)): two-wave workgroups as bm_scan.
+            uint32_t q = g_tune[1] ? (uint32_t)g_tune[1] : a.halo;  // tune(1, q): experiments
+            while (q > 1 && w % q) q /= 2;
+            const bool busy = g_tune[2] ? g_tune[2] == 2 : !a.sparse;  // tune(2, 1 / 2): four-wave / two-wave workgroups
+#define SG_BNDM(T_, WGS_, Q_)                                                                            \
+    do {                                                                                                  \
+        const size_t lds = 1024 + LaneTile<kBndmHalo>::bytes(T_);                                         \
+        const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)(T_) * kBndmL);      \
+        if (m > 32) return launch_tiled(bndm_scan<T_, kBndmL, true, Q_>, a, tr, T_, lds, WGS_, num_cus, stream); \
+        return launch_tiled(bndm_scan<T_, kBndmL, false, Q_>, a, tr, T_, lds, WGS_, num_cus, stream);     \
+    } while (0)
+            if (busy) {
+                if (q == 8) SG_BNDM(kBndmBusyT, 10, 8);
+                if (q == 4) SG_BNDM(kBndmBusyT, 10, 4);
+                if (q == 2) SG_BNDM(kBndmBusyT, 10, 2);
+                SG_BNDM(kBndmBusyT, 10, 1);
+            }
+            const int wgs = tile_wgs(a);
+            if (q == 8) SG_BNDM(kBndmT, wgs, 8);
+            if (q == 4) SG_BNDM(kBndmT, wgs, 4);
+            if (q == 2) SG_BNDM(kBndmT, wgs, 2);
+            SG_BNDM(kBndmT, wgs, 1);
+#undef SG_BNDM
         }
         case SMARTGPU_SA:  // Shift-And: so_runs1<.., AND = true>; the A/B kernels below are Shift-Or only
         case SMARTGPU_SO: {

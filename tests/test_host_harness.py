@@ -79,7 +79,7 @@ def test_smart_report_lines(tmp_path):
         assert line and "[OK]" in line[0] and "occ 1" in line[0] and "GB/s" in line[0], (name, out)
         assert re.search(r"\d+\.\d\d+ \+ \d+\.\d\d+ ms", line[0])  # %.2f as the reference above 1 ms, %.4f below
         # GB/s, its share of the HBM-read roofline, the GPUs, the kernel that ran (SURVEY.md §5 metrics row)
-        assert re.search(r"\d+\.\d GB/s\t\d+\.\d% of 1 x 8 TB/s\t(hor_scan|bm_scan|kmp_runs|so_runs|bndm_scan|packed_scan|hor_scan_bp|bndml_scan)$", line[0]), line[0]
+        assert re.search(r"\d+\.\d GB/s\t\d+\.\d% of 1 x 8 TB/s\t(hor_scan|bm_scan|kmp_runs|so_runs|bndm_scan|sbndm_scan|packed_scan|hor_scan_bp|bndml_scan)$", line[0]), line[0]
     table = list((tmp_path / "results").glob("EXP*/rand128.txt"))
     assert table and table[0].read_text().startswith("HOR")
     xml = list((tmp_path / "results").glob("EXP*/rand128.xml"))[0].read_text()

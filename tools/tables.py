@@ -9,7 +9,7 @@ ROW = re.compile(r"^(\w+)\s+m=(\d+)\s+sigma=(\d+)\s+([\d.]+) ms.*?([\d.]+) GB/s\
 ORDER = ["hor", "bm", "kmp", "so", "bndm", "epsm", "sa", "qs", "tunedbm", "raita", "hash3", "hash5", "hash8", "sbndm", "kr", "bndml"]
 OWN = {"hor": "hor_scan", "bm": "bm_scan", "kmp": "kmp_runs", "so": "so_runs", "bndm": "bndm_scan", "epsm": "packed_scan",
        "sa": "so_runs", "qs": "hor_scan", "tunedbm": "hor_scan", "raita": "hor_scan", "hash3": "hor_scan", "hash5": "hor_scan",
-       "hash8": "hor_scan", "sbndm": "bndm_scan", "kr": "hor_scan_bp", "bndml": "bndml_scan"}
+       "hash8": "hor_scan", "sbndm": "sbndm_scan", "kr": "hor_scan_bp", "bndml": "bndml_scan"}
 MARK = {"packed_scan": "p", "so_runs": "s"}
 
 
