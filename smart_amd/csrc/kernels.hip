@@ -246,6 +246,60 @@ struct LaneTile {
     }
 };
 
+// Column tiles (bndm_scan): the text of a tile as a dword matrix [kColRows rows][THREADS columns], every lane's 64-byte
+// segment DOWN its own column behind a copy of the 32 bytes before it — rows 0..7: T[seg-32, seg), rows 8..23: the
+// segment, row 24: never filled (a three-dword read may touch it).  A row is THREADS * 4 bytes, a multiple of 128: the
+// LDS bank of a dword is its column mod 32 whatever the row, so a wave whose lanes read ANY rows of their own columns
+// reads conflict-free (a flat tile, swizzled or padded, serves such a gather in three to four passes, and an unaligned
+// ds_read_b32 stalls on top: bndm_scan on lane tiles, rand4 m = 32: LDS 82 % busy, 52 % of that SQ_LDS_UNALIGNED_STALL,
+// profiles/r03/c_pmc_bndm_lanetile.txt).  A q-gram is two or three ALIGNED dwords a row apart — one ds_read2st64_b32 —
+// and v_alignbyte_b32.
+// Parking without a transpose in registers: the coalesced loads leave lane (Q, p) = (tid / 4, tid % 4) with quarter p of
+// the four segments r * G + Q (r = 0..3, G = THREADS / 4).  Written straight, the four lanes of a quad would hit ONE
+// column, one bank, four times; so segment s lives in column col(s) = s with its low five bits rotated by 8 * (s / G),
+// and in step t lane (Q, p) writes its quarter of segment ((p + t) % 4) * G + Q: the quads of a half-wave then cover the
+// 32 banks exactly once.  Which register that is depends on p: the four chunks are rotated by p once (two conditional
+// stages, 32 v_cndmask), after which step t writes register t.
+constexpr uint32_t kColRows = 25;
+template <int THREADS>
+struct ColTile {
+    static constexpr uint32_t RS = THREADS * 4u, G = THREADS / 4u;
+    static_assert(RS % 128 == 0, "the bank of a dword must not depend on its row");
+    static __host__ __device__ constexpr uint32_t bytes() { return kColRows * RS; }
+    static __device__ __forceinline__ uint32_t col(uint32_t s) { return (s & ~31u) | ((s + 8u * (s / G)) & 31u); }
+    // the lane's four chunks (row r of the tile's coalesced loads in e[r]) and, from threads 0 and 1, the 32 bytes
+    // in front of the tile (front)
+    static __device__ __forceinline__ void park(uint8_t* txt, uint4 (&e)[4], const uint4& front)
+    {
+        const uint32_t tid = threadIdx.x, Q = tid >> 2, p = tid & 3u;
+        {   // e[t] <- e[(t + p) % 4]
+            const bool b0 = p & 1u, b1 = p & 2u;
+            const uint4 a0 = e[0], a1 = e[1], a2 = e[2], a3 = e[3];
+#define SG_SEL(c_, x_, y_) make_uint4((c_) ? (x_).x : (y_).x, (c_) ? (x_).y : (y_).y, (c_) ? (x_).z : (y_).z, (c_) ? (x_).w : (y_).w)
+            const uint4 c0 = SG_SEL(b0, a1, a0), c1 = SG_SEL(b0, a2, a1), c2 = SG_SEL(b0, a3, a2), c3 = SG_SEL(b0, a0, a3);
+            e[0] = SG_SEL(b1, c2, c0);
+            e[1] = SG_SEL(b1, c3, c1);
+            e[2] = SG_SEL(b1, c0, c2);
+            e[3] = SG_SEL(b1, c1, c3);
+#undef SG_SEL
+        }
+#pragma unroll
+        for (uint32_t t = 0; t < 4; ++t) {
+            const uint32_t s = ((p + t) & 3u) * G + Q;  // the segment whose quarter p is in e[t]
+            uint32_t* d = reinterpret_cast<uint32_t*>(txt + (8u + 4u * p) * RS + col(s) * 4u);
+            d[0] = e[t].x; d[RS / 4] = e[t].y; d[2 * RS / 4] = e[t].z; d[3 * RS / 4] = e[t].w;
+            if (p >= 2 && s + 1 < (uint32_t)THREADS) {  // the segment's last 32 bytes: also in front of the next one
+                uint32_t* h = reinterpret_cast<uint32_t*>(txt + (4u * (p - 2)) * RS + col(s + 1) * 4u);
+                h[0] = e[t].x; h[RS / 4] = e[t].y; h[2 * RS / 4] = e[t].z; h[3 * RS / 4] = e[t].w;
+            }
+        }
+        if (tid < 2) {  // segment 0's copy of T[tile0 - 32, tile0): column col(0) = 0, rows 4 tid ..
+            uint32_t* h = reinterpret_cast<uint32_t*>(txt + (4u * tid) * RS);
+            h[0] = front.x; h[RS / 4] = front.y; h[2 * RS / 4] = front.z; h[3 * RS / 4] = front.w;
+        }
+    }
+};
+
 // ---------------------------------------------------------------------------
 // Horspool  (reference: src/algos/hor.c:26-51)
 // LDS: u16 tab[256] | pattern tail P[m-1-H..m-1] | text [tile0-H16, tile0+TB)
@@ -711,7 +765,7 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_fi
 // ---------------------------------------------------------------------------
 // BNDM with q-grams, 32-bit words like the reference  (src/algos/bndm.c:27-111; reading q bytes of a window at
 // once is bndmq2.c / bndmq4.c:29-72's idea).  w = min(m,32); tiles are indexed by the END of the w-byte (prefix) window.
-// LDS: u32 B[256] (left-aligned: B[c] << (32-w)) | lane tile (LaneTile<kBndmHalo>)
+// LDS: u32 B[256] (left-aligned: B[c] << (32-w)) | column tile (ColTile)
 //
 // One flat loop over (e, k, D) — window end, bytes of the window read, the factors of P still alive — in which every
 // iteration reads the NEXT Q BYTES of the window, T[e-k-Q+1 .. e-k], with ONE unaligned LDS read, looks up their Q
@@ -736,8 +790,8 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
 {
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
-    using LT = LaneTile<kBndmHalo>;  // a window reaches 31 bytes back
-    static_assert(L == 64 && kBndmHalo >= 32 + 4 && (Q == 1 || Q == 2 || Q == 4 || Q == 8), "Q divides 32: no read leaves the window's 32 bytes");
+    using CT = ColTile<THREADS>;  // a window reaches 31 bytes back: the 32 bytes in front of every segment
+    static_assert(L == 64 && (Q == 1 || Q == 2 || Q == 4 || Q == 8), "Q divides 32: no read leaves the window's 32 bytes");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32;
     uint32_t* B = reinterpret_cast<uint32_t*>(smem);
@@ -752,27 +806,24 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
 
     const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
     uint32_t hits = 0;
-    uint4 p0, p1, p2, p3, ph;  // prefetch registers: 4 tile rows + (threads 0, 1) the 32 bytes in front of the tile
+    uint4 pre[4], ph;  // prefetch registers: 4 tile rows + (threads 0, 1) the 32 bytes in front of the tile
     auto issue = [&](uint64_t tile0) {
         const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
-        p0 = ld_stream16(src);
-        p1 = ld_stream16(src + THREADS * 16);
-        p2 = ld_stream16(src + THREADS * 32);
-        p3 = ld_stream16(src + THREADS * 48);
-        if (threadIdx.x < LT::DUP / 16) ph = ld_stream16(src - LT::DUP);
+        pre[0] = ld_stream16(src);
+        pre[1] = ld_stream16(src + THREADS * 16);
+        pre[2] = ld_stream16(src + THREADS * 32);
+        pre[3] = ld_stream16(src + THREADS * 48);
+        if (threadIdx.x < 2) ph = ld_stream16(src - 32);
     };
     const uint64_t t_end = tile_first + ntiles;
     uint64_t t = tile_first + blockIdx.x;
     issue(t * TB);
-    const uint32_t own = kTxt + threadIdx.x * LT::STRIDE + kBndmHalo;  // LDS offset of the lane's own first byte
+    // the lane's column; a cursor is a byte position in it: 32 + x for byte x of the segment, 0..31 the bytes before
+    const uint32_t col4 = kTxt + CT::col(threadIdx.x) * 4u;
     for (; t < t_end; t += gridDim.x) {
         const uint64_t tile0 = t * TB;
         __syncthreads();
-        LT::park(txt, threadIdx.x, p0, THREADS);
-        LT::park(txt, THREADS + threadIdx.x, p1, THREADS);
-        LT::park(txt, 2 * THREADS + threadIdx.x, p2, THREADS);
-        LT::park(txt, 3 * THREADS + threadIdx.x, p3, THREADS);
-        if (threadIdx.x < LT::DUP / 16) LT::park_front(txt, threadIdx.x, ph);
+        CT::park(txt, pre, ph);
         __syncthreads();
         if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
         // window ends [x0, x1) of the lane's segment are its own
@@ -786,13 +837,26 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
         }
         bool parked = false;  // first candidate of this tile awaiting wave_verify
         const uint8_t* parked_at = a.text;
-        uint32_t e = own + x0, k = 0, D = 0xFFFFFFFFu;
-        const uint32_t ehi = own + x1;
+        uint32_t e = 32u + x0, k = 0, D = 0xFFFFFFFFu;
+        const uint32_t ehi = 32u + x1;
         while (e < ehi) {
             // the window's next Q bytes, T[e-k-Q+1 .. e-k]: byte Q-1 of X is the one bndm.c:50 reads first (right to left)
             uint32_t xw[2] = {0u, 0u};
-            if (Q == 1) xw[0] = smem[e - k];
-            else __builtin_memcpy(xw, smem + (e - k - (Q - 1)), Q);
+            {
+                const uint32_t pl = e - k - (Q - 1);  // position of the lowest of them
+                const uint32_t at = col4 + (pl >> 2) * CT::RS;
+                if (Q == 1) {
+                    xw[0] = smem[at + (pl & 3u)];
+                } else {
+                    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(smem + at);
+                    const uint32_t w1 = *reinterpret_cast<const uint32_t*>(smem + at + CT::RS);
+                    xw[0] = __builtin_amdgcn_alignbyte(w1, w0, pl);
+                    if (Q == 8) {
+                        const uint32_t w2 = *reinterpret_cast<const uint32_t*>(smem + at + 2 * CT::RS);
+                        xw[1] = __builtin_amdgcn_alignbyte(w2, w1, pl);
+                    }
+                }
+            }
             uint32_t G = 0xFFFFFFFFu;
 #pragma unroll
             for (int j = 0; j < Q; ++j) {  // step j reads byte Q-1-j; its mask meets D after Q-1-j more shifts
@@ -809,7 +873,7 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
                 hits += occ;
             } else if (__any(occ)) {  // rare, wave-uniform: the 32-byte prefix matched, verify P[32..m) (bndm.c:99-102)
                 if (occ) {
-                    const uint8_t* rest = a.text + seg + (e - own) + 1;  // = text + s + w; inside the text because s < s_end
+                    const uint8_t* rest = a.text + seg + (e - 32u) + 1;  // = text + s + w; inside the text because s < s_end
                     if (!parked) {
                         parked = true;
                         parked_at = rest;
@@ -2612,7 +2676,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
             const bool busy = g_tune[2] ? g_tune[2] == 2 : !a.sparse;  // tune(2, 1 / 2): four-wave / two-wave workgroups
 #define SG_BNDM(T_, WGS_, Q_)                                                                            \
     do {                                                                                                  \
-        const size_t lds = 1024 + LaneTile<kBndmHalo>::bytes(T_);                                         \
+        const size_t lds = 1024 + ColTile<T_>::bytes();                                                   \
         const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)(T_) * kBndmL);      \
         if (m > 32) return launch_tiled(bndm_scan<T_, kBndmL, true, Q_>, a, tr, T_, lds, WGS_, num_cus, stream); \
         return launch_tiled(bndm_scan<T_, kBndmL, false, Q_>, a, tr, T_, lds, WGS_, num_cus, stream);     \
