@@ -226,7 +226,8 @@ int smartgpu_probe_read_ms(const smartgpu_text *t, int reps, double *ms_per_pass
  *      the algorithm's own LDS-tile skip loop / 1 always the algorithm's own skip
  *      loop / 2 Horspool's bank-private LDS layout / 3 always the packed matcher
  *   1  bndm_scan: bytes of a window read per iteration (1, 2, 4, 8; 0 = the plan's choice from the pattern)
- *   2  bm_scan / bndm_scan workgroups: 1 four waves / 2 two waves (0 = by the pattern: two where its symbols repeat)
+ *   2  bm_scan / bndm_scan workgroups: 1 four waves / 2 two waves (0 = default: bm_scan two where the pattern's symbols
+ *      repeat, bndm_scan always four)
  *   3  KMP: 0 kmp_runs (transition table) / 1 kmp_scan (LDS tiles, m <= 40) / 2 kmp_links_runs
  *      (failure links followed per byte)
  *   5  run length in bytes of the runs kernels (so_runs, kmp_runs); 0 = default

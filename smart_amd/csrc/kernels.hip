@@ -2669,11 +2669,17 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
                 if (m > 32) return launch_tiled(sbndm_scan<kBndmT, kBndmL, true, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
                 return launch_tiled(sbndm_scan<kBndmT, kBndmL, false, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
             }
-            // BNDM (and BNDML's m <= 32): q bytes of a window per iteration, q = a.halo from the plan (api.cpp bndm_q).
-            // Patterns whose symbols repeat (a.sparse == 0; only under tune(0,1)): two-wave workgroups as bm_scan.
+            // BNDM (and BNDML's m <= 32): q bytes of a window per iteration, q = a.halo from the plan (api.cpp build_blob).
+            // Workgroups per CU (26.6 KB of LDS each, six fit), measured on 1 GiB (ms): a streaming scan (a.sparse,
+            // rand128 m = 16 / 32 / 256) 0.170 / 0.160 / 0.173 with FOUR (five: 0.176 / 0.178 / 0.184); where windows
+            // survive — English m = 16 / 32 / 256: 0.179 / 0.179 / 0.185 with FIVE (four: 0.179 / 0.174 / 0.204, six:
+            // 0.183 / 0.182 / 0.192); a small alphabet (q >= 4), rand4 m = 16 / 32, rand2 m = 32: 0.185 / 0.172 / 0.195
+            // with SIX (four: 0.202 / 0.165 / 0.214).  Two-wave workgroups (tune(2,2)) were never ahead: 8 of them
+            // 0.190 / 0.171 / 0.200 on the small alphabets, 0.177 / 0.172 / 0.180 on English.
             uint32_t q = g_tune[1] ? (uint32_t)g_tune[1] : a.halo;  // tune(1, q): experiments
             while (q > 1 && w % q) q /= 2;
-            const bool busy = g_tune[2] ? g_tune[2] == 2 : !a.sparse;  // tune(2, 1 / 2): four-wave / two-wave workgroups
+            const bool two_wave = g_tune[2] == 2;
+            const int wgs = a.sparse ? 4 : q >= 4 ? 6 : 5;
 #define SG_BNDM(T_, WGS_, Q_)                                                                            \
     do {                                                                                                  \
         const size_t lds = 1024 + ColTile<T_>::bytes();                                                   \
@@ -2681,13 +2687,12 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
         if (m > 32) return launch_tiled(bndm_scan<T_, kBndmL, true, Q_>, a, tr, T_, lds, WGS_, num_cus, stream); \
         return launch_tiled(bndm_scan<T_, kBndmL, false, Q_>, a, tr, T_, lds, WGS_, num_cus, stream);     \
     } while (0)
-            if (busy) {
-                if (q == 8) SG_BNDM(kBndmBusyT, 10, 8);
-                if (q == 4) SG_BNDM(kBndmBusyT, 10, 4);
-                if (q == 2) SG_BNDM(kBndmBusyT, 10, 2);
-                SG_BNDM(kBndmBusyT, 10, 1);
+            if (two_wave) {
+                if (q == 8) SG_BNDM(kBndmBusyT, 2 * wgs, 8);
+                if (q == 4) SG_BNDM(kBndmBusyT, 2 * wgs, 4);
+                if (q == 2) SG_BNDM(kBndmBusyT, 2 * wgs, 2);
+                SG_BNDM(kBndmBusyT, 2 * wgs, 1);
             }
-            const int wgs = tile_wgs(a);
             if (q == 8) SG_BNDM(kBndmT, wgs, 8);
             if (q == 4) SG_BNDM(kBndmT, wgs, 4);
             if (q == 2) SG_BNDM(kBndmT, wgs, 2);
