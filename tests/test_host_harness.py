@@ -69,7 +69,7 @@ def test_reference_cases_through_plugin_shape(algo):
 @pytest.mark.gpu
 def test_smart_report_lines(tmp_path):
     r = run("smart", "-text", "rand128", "-plen", "32", "32", "-pset", "5", "-occ", "-pre", "-dif", "-std", "-txt",
-            "-tex", "-php", cwd=str(tmp_path))
+            "-tex", "-php", "-tb", "60000", cwd=str(tmp_path))  # -tb: a hiccup of a shared box must not turn a row into [OUT]
     assert r.returncode == 0, r.stdout + r.stderr
     out = r.stdout
     assert "Searching for a set of 5 patterns with length 32" in out
@@ -113,18 +113,19 @@ def test_smart_gpus_rehearsal_on_one_box(tmp_path):
     """`smart -gpus 3` (smart.c:140-146's call replaced by the sharded smartgpu_msearch_batch64) on a box
     with fewer GPUs: SMARTGPU_REDUCE_HOST=1 puts shard g on GPU g mod visible and adds the counts on the
     host.  The harness path, its shard arithmetic and its report columns run; the times mean nothing."""
-    r = run("smart", "-text", "rand4", "-plen", "2", "64", "-pset", "4", "-occ", "-seed", "7", "-gpus", "3", "-algo", "hor,bm,kmp,so,bndm,epsm",
+    r = run("smart", "-text", "rand4", "-plen", "2", "64", "-pset", "4", "-occ", "-seed", "7", "-tb", "60000", "-gpus", "3", "-algo", "hor,bm,kmp,so,bndm,epsm",
             cwd=str(tmp_path), env={"SMARTGPU_REDUCE_HOST": "1"})
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Text sharded over 3 GPUs" in r.stdout and "on the host (SMARTGPU_REDUCE_HOST: rehearsal)" in r.stdout
-    one = run("smart", "-text", "rand4", "-plen", "2", "64", "-pset", "4", "-occ", "-seed", "7", "-algo", "hor,bm,kmp,so,bndm,epsm", cwd=str(tmp_path))
+    one = run("smart", "-text", "rand4", "-plen", "2", "64", "-pset", "4", "-occ", "-seed", "7", "-tb", "60000", "-algo", "hor,bm,kmp,so,bndm,epsm", cwd=str(tmp_path))
     assert one.returncode == 0, one.stdout + one.stderr
     rows = [ln for ln in r.stdout.splitlines() if "[OK]" in ln]
     assert len(rows) == 6 * 6 and all("% of 3 x 8 TB/s" in ln for ln in rows), r.stdout
     assert "[ERROR]" not in r.stdout and "[--]" not in r.stdout
     # same seed, same generated corpus: the same patterns, so the sharded run reports the very same occurrence means
     occ = lambda out: re.findall(r"\] (\w+) \..*\[OK\].*occ (\d+)", out)  # noqa: E731
-    assert occ(r.stdout) == occ(one.stdout) and len(occ(one.stdout)) == 36
+    # (-tb 60000: the default 300 ms limit turns a row into [OUT] when a shared box hiccups — seen once in five runs)
+    assert occ(r.stdout) == occ(one.stdout) and len(occ(one.stdout)) == 36, (r.stdout, one.stdout)
     xml = list((tmp_path / "results").glob("EXP*/rand4.xml"))
     assert any("<GPUS>3</GPUS>" in x.read_text() for x in xml)
     # without the rehearsal switch more GPUs than the box has is an error, not a silent fallback
