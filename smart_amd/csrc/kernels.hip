@@ -1215,6 +1215,11 @@ __device__ __forceinline__ uint32_t kmp_delta(uint32_t dword, uint32_t st, int b
 // 256-byte bank row (no padding, no conflicts).
 // ---------------------------------------------------------------------------
 constexpr uint32_t kRunLine = 128;       // bytes of a run fetched per step
+// The swap loader reads whole lines of 8 runs per instruction and up to 7 runs + a few lines past the text's last run
+// (blocks past the last run re-read block 0, a partial block does not): that over-read must stay inside the text's
+// back pad, which bounds the run length — smartgpu_tune(5, .) is clamped to it (launch_so_runs, launch_kmp_runs).
+constexpr uint64_t kRunLenMax = 16384;   // runs of at most 16 KiB (the default: 2-4 KiB, 8 x 254 for the longest KMP window)
+static_assert(8 * kRunLenMax + 512 + 4200 <= kBackPad, "the loaders' over-read past the last run must stay inside the back pad");
 constexpr int kLineSlab = 64 * 64;       // LDS bytes per wave
 constexpr int kRunWaves = 16;            // one 1024-thread workgroup per CU shares the table
 
@@ -2355,7 +2360,7 @@ static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus,
 {
     // bank-private table: 64 KB shared by the 16 waves of ONE workgroup per CU
     const uint32_t m = a.m;
-    const uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
+    const uint64_t lmin = g_tune[5] ? std::min<uint64_t>((uint64_t)g_tune[5], kRunLenMax / 2) : 2048;
     const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin, 128);
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
@@ -2425,7 +2430,7 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     const size_t lds = table + kKmpQBytes + kRunWaves * (size_t)kLineSlab;
     // runs of 2-4 KiB: at least 8x the w-1 bytes a run re-scans, at most 8 KiB (the loader's
     // over-read past the last run stays inside the text's back pad)
-    uint64_t lmin = g_tune[5] ? (uint64_t)g_tune[5] : 2048;
+    uint64_t lmin = g_tune[5] ? std::min<uint64_t>((uint64_t)g_tune[5], kRunLenMax / 2) : 2048;
     if (lmin < 8ull * (w - 1)) lmin = 8ull * (w - 1);
     const uint64_t lfloor = 2ull * (w - 1) > 128 ? 2ull * (w - 1) : 128;  // small texts: see balanced_run_len
     const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin, lfloor);
