@@ -448,7 +448,9 @@ NAMED_IN = {"hor": (5,), "bm": (4, 5), "kmp": (5,), "so": (3, 5), "bndm": (3,), 
 def own_kernel_summary(cells):
     """Per algorithm: the worst cell measured ON THE ALGORITHM'S OWN KERNEL (a cell the plan did not
     reroute, or the cell's second entry under smartgpu_tune(0,1)) on rand128 m in {4..256} and on
-    each configuration that names the algorithm: [frac, "sigma/m"]."""
+    each configuration that names the algorithm: [frac, "sigma/m", worst frac among the cells with
+    m >= 16] — below 16 bytes a skip loop visits a window every byte or two and is iteration-bound
+    on any text."""
     out = {}
     for algo, own in OWN_KERNEL.items():
         mine = [c for c in cells if c["algo"] == algo and c["kernel"] == own and "kernels" not in c]
@@ -457,7 +459,8 @@ def own_kernel_summary(cells):
             got = [c for c in mine if sel(c)]
             if got:
                 w = min(got, key=lambda c: c["frac"])
-                entry[label] = [w["frac"], "%s/m%d" % (w["sigma"], w["m"])]
+                long_ = [c["frac"] for c in got if c["m"] >= 16]
+                entry[label] = [w["frac"], "%s/m%d" % (w["sigma"], w["m"]), min(long_) if long_ else None]
         out[algo] = entry
     return out
 

@@ -252,7 +252,7 @@ struct LaneTile {
 // LDS bank of a dword is its column mod 32 whatever the row, so a wave whose lanes read ANY rows of their own columns
 // reads conflict-free (a flat tile, swizzled or padded, serves such a gather in three to four passes, and an unaligned
 // ds_read_b32 stalls on top: bndm_scan on lane tiles, rand4 m = 32: LDS 82 % busy, 52 % of that SQ_LDS_UNALIGNED_STALL,
-// profiles/r03/c_pmc_bndm_lanetile.txt).  A q-gram is two or three ALIGNED dwords a row apart — one ds_read2st64_b32 —
+// profiles/r03/c_pmc_bndm_rand4_m32.txt).  A q-gram is two or three ALIGNED dwords a row apart — one ds_read2st64_b32 —
 // and v_alignbyte_b32.
 // Parking without a transpose in registers: the coalesced loads leave lane (Q, p) = (tid / 4, tid % 4) with quarter p of
 // the four segments r * G + Q (r = 0..3, G = THREADS / 4).  Written straight, the four lanes of a quad would hit ONE
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a1, uint64_t 
 // and moves on by gs[0] (bm.c:86; bc[.] - m <= 0), the lane counts it on the way.
 // Round 2's loop opened a window with two folded tables and walked a surviving one in a nested loop: while one lane
 // compared, the other 63 stood still, and every level of the nest was paid in exec-mask bookkeeping — 4.9 SCALAR
-// instructions per text byte and lane next to 3.0 vector ones on English (m = 128, profiles/r03/a_pmc_bm_english.txt:
+// instructions per text byte and lane next to 3.0 vector ones on English (m = 128, profiles/r03/b_pmc_bm_english_m128.txt:
 // the CU's one scalar unit ~90 % busy).  Here a lane that compares and a lane that opens its next window run the
 // same instructions; the only branches are the loop's own and, for long patterns, one wave-uniform test.
 // ---------------------------------------------------------------------------

@@ -57,7 +57,7 @@ def test_compact_line_keeps_the_contract_under_4k():
              for a in bench.OWN_KERNEL for m in (2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096) for own in (False, True)]
     own = bench.own_kernel_summary(cells)
     assert set(own) == set(bench.OWN_KERNEL) and own["bm"].keys() == {"rand128", "config4", "config5"}
-    assert own["bndm"]["config3"][1] in ("4/m2", "2/m2")
+    assert own["bndm"]["config3"][1] in ("4/m2", "2/m2") and own["bndm"]["config3"][2] >= own["bndm"]["config3"][0]
     out = {"metric": "x", "value": 1.0, "unit": "GB/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 0.1,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
            "config": {"workload": "w", "corpus": "c" * 300, "prewarm": "p" * 300, "sharding": "s" * 300},
