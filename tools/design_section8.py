@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Rewrite DESIGN.md §8's headline paragraph numbers and every table from one session's files in profiles/r02/:
-    python tools/design_section8.py g
-(the prose between the tables is kept as it stands; tables are matched by the heading line in front of them)."""
+"""Rewrite every table of DESIGN.md §8 from one session's files in profiles/<round>/ and print the numbers its prose quotes:
+    python tools/design_section8.py a r03
+(the prose between the tables is kept as it stands; tables are matched in the order they appear)."""
 import csv
 import json
 import re
@@ -9,7 +9,8 @@ import subprocess
 import sys
 
 prefix = sys.argv[1]
-root = "profiles/r02/%s_" % prefix
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+root = "profiles/%s/%s_" % (rnd, prefix)
 
 
 def tab(name):
@@ -18,7 +19,7 @@ def tab(name):
 
 
 s = open("DESIGN.md").read()
-a = s.index("## 8. Round-2 results")
+a = s.index("## 8. Round-%d results" % int(rnd[1:]))
 head, body = s[:a], s[a:]
 # tables, in the order they appear
 order = ["sweep_rand128_full", "sweep_rand128_own", "sweep_rand4", "sweep_rand2", "sweep_rand4_own", "sweep_rand2_own",
@@ -28,7 +29,7 @@ blocks = re.findall(r"(?:^\|.*\n)+", body, flags=re.M)
 assert len(blocks) == len(order), (len(blocks), len(order))
 for old, name in zip(blocks, order):
     body = body.replace(old, tab(name) + "\n", 1)
-body = re.sub(r"profiles/r02/[a-z]_sweep_", "profiles/r02/%s_sweep_" % prefix, body)
+body = re.sub(r"profiles/%s/[a-z]_sweep_" % rnd, "profiles/%s/%s_sweep_" % (rnd, prefix), body)
 body = re.sub(r"`[a-z]_pytest_gpu.log`", "`%s_pytest_gpu.log`" % prefix, body)
 body = re.sub(r"`[a-z]_bench_default.json`", "`%s_bench_default.json`" % prefix, body)
 body = re.sub(r"`[a-z]_bench_pmc_summary.csv`", "`%s_bench_pmc_summary.csv`" % prefix, body)
@@ -52,4 +53,5 @@ print("headline: %.2f TB/s = %.1f %% of 8 TB/s = %.0f %% of stream; kernel %.4f 
                                (r["traffic"] or 0) / 2**30))
 print("pmc ratios:", {k: round(ratio(*k[:2]), 3) for k in pm if k[2] == "FETCH_SIZE" and k[1].endswith(("_runs", "_scan"))})
 print("cpu:", d["cpu_baseline"]["value"], d["cpu_baseline"]["all_cores"])
-print("min_frac:", d["min_frac"], "cells", len(d["sweep"]))
+print("min_frac:", d["min_frac"], "cells", d.get("sweep_cells"))
+print("own_kernel_min:", d.get("own_kernel_min"))
