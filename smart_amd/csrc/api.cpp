@@ -203,6 +203,7 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
     bool repeats_short = false;  // 7 bytes or fewer with a symbol that occurs twice (a small alphabet, most likely)
     uint64_t pairs = 0;          // ordered pairs of equal symbols in P: pairs / (m (m-1)) estimates P(two symbols are equal)
     uint32_t distinct = 0;       // symbols that occur in P
+    uint32_t bndm_q_wanted = 1;  // BNDM: the q its statistics ask for (the plan's q also has to divide the window)
     {
         uint32_t cnt[256] = {0};
         for (uint32_t i = 0; i < m; ++i) distinct += cnt[P[i]]++ == 0;
@@ -338,6 +339,7 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
                     if (survive < 0.3) break;
                     q *= 2;
                 }
+                bndm_q_wanted = q;
                 while (w % q) q /= 2;  // q | w: a window is read through in whole iterations
                 *halo = q;
             }
@@ -421,7 +423,20 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
         //   the every-byte kernels win there; so_runs and the packed matcher are equal on rand128 (76-77 %), so_runs
         //   ahead on everything else (rand256, rand32, English at m = 2, 4: 78-81 % against 67-76 %).
         bool to_so = (algo == SMARTGPU_KR || algo == SMARTGPU_KMP) ? true : (repeats || repeats_short || m <= sg::short_pattern_max_m(algo)) && algo != SMARTGPU_EPSM;
-        if (!to_so && m >= 8) {  // (8 bytes of distinct symbols estimate 16/8^4 = 0.004: below that the histogram says nothing)
+        // Round 3: where the algorithm's OWN kernel holds on such patterns, it keeps them (a configuration that
+        // names Boyer-Moore or BNDM should not be a Shift-Or measurement).  bm_scan's flat loop: 72-74 % on English from 8
+        // bytes on (so_runs 79-81 %); an alphabet of a few symbols shifts it by a byte or two (16-60 %): stays with so_runs.
+        // bndm_scan with q-grams: 74-79 % on four symbols and 75-76 % on English from 16 bytes on, 66-71 % on two from 32
+        // (q = 8); below those lengths it is iteration-bound.
+        bool own_holds = false;
+        // (hor_scan's flat form, VAR 9, for Horspool and Tuned BM: 68-70 % on English and rand32 from 8 bytes on)
+        if (algo == SMARTGPU_BM || algo == SMARTGPU_HOR || algo == SMARTGPU_TUNEDBM)
+            own_holds = m >= 8 && !(distinct <= 8 && 2 * distinct <= m);  // not: a few symbols, each several times
+        if (algo == SMARTGPU_BNDM || (algo == SMARTGPU_BNDML && m <= 32)) own_holds = *halo == bndm_q_wanted && (*halo >= 8 ? m >= 32 : m >= 16);  // *halo: bndm_scan's q
+        if (own_holds && m > sg::short_pattern_max_m(algo)) {
+            to_so = false;
+            *prefer_packed = 0;
+        } else if (!to_so && m >= 8) {  // (8 bytes of distinct symbols estimate 16/8^4 = 0.004: below that the histogram says nothing)
             uint32_t cnt[256] = {0};
             for (uint32_t i = 0; i < m; ++i) ++cnt[P[i]];
             double pass = 16.0;

@@ -316,9 +316,99 @@ struct ColTile {
 //      windows are tested right to left through the halo and completed in memory as in 0
 //   2  Quick Search (qs.c:27-52): the shift comes from the byte AFTER the window, T[s+m]; the
 //      tile carries 16 more bytes at its end for it
+//   9  Horspool again, the flat form for patterns whose symbols repeat (hor_flat above)
 //   3, 5, 8  Lecroq's HASHq (hash3.c:28-84, hash5.c, hash8.c): the table is indexed by an 8-bit hash
 //      of the window's last q = VAR bytes, h = sum T[e-k] * 2^k mod 256; its zero entry (the hash
 //      of the pattern's last q-gram) is the flag, stored with the shift applied after a candidate
+// Horspool, the flat form (VAR = 9; hor.c:33-51) for patterns whose symbols repeat (a.sparse == 0: natural language,
+// medium alphabets): where windows survive their first comparison the loop below makes a wave wait for its one lane
+// that walks.  As bm_scan: ONE loop over (e, k, sh) on lane tiles — a text byte c = T[e-k], the pattern byte P[m-1-k]
+// and bc[c] per iteration; k = 0 opens a window and takes hbc[T[e]] with it (hor.c:49: the shift is always the LAST
+// byte's), equal bytes walk on, the first unequal one — or the H+1-th equal one: an occurrence, or (LONG) a candidate
+// for memory — moves the window.  A pure streaming scan (rand128: the headline) keeps the loop below: two LDS reads
+// per window and a cheaper tile.
+// LDS: u16 bc[256] | u8 ptail[32] (ptail[k] = P[m-1-k]) | lane tile (LaneTile<kBmHalo>)
+template <int THREADS, int L, bool LONG>
+__device__ __forceinline__ void hor_flat(const ScanArgs& a, uint64_t tile_first, uint32_t ntiles, uint8_t* smem)
+{
+    constexpr int TB = THREADS * L;
+    using LT = LaneTile<kBmHalo>;
+    static_assert(L == 64 && kBmHalo >= kHaloMax, "a lane owns one 64-byte segment of a lane tile");
+    const uint32_t m = a.m, H = a.halo;
+    uint16_t* bc = reinterpret_cast<uint16_t*>(smem);
+    uint8_t* ptail = smem + 512;
+    constexpr uint32_t kTxt = 512 + 32;
+    uint8_t* txt = smem + kTxt;
+    for (uint32_t i = threadIdx.x; i < 256; i += THREADS) bc[i] = reinterpret_cast<const uint16_t*>(a.blob + kTableOff)[i] & 0x7FFFu;
+    for (uint32_t k = threadIdx.x; k < 32; k += THREADS) ptail[k] = k <= H ? a.blob[m - 1 - k] : 0;
+
+    const uint64_t e_begin = a.s_begin + m - 1, e_end = a.s_end + m - 1;
+    uint32_t hits = 0;
+    uint4 p0, p1, p2, p3, ph;  // prefetch registers: 4 tile rows + the 16 bytes in front of the tile
+    auto issue = [&](uint64_t tile0) {
+        const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
+        p0 = ld_stream16(src);
+        p1 = ld_stream16(src + THREADS * 16);
+        p2 = ld_stream16(src + THREADS * 32);
+        p3 = ld_stream16(src + THREADS * 48);
+        if (threadIdx.x == 0) ph = ld_stream16(src - LT::DUP);
+    };
+    const uint64_t t_end = tile_first + ntiles;
+    uint64_t t = tile_first + blockIdx.x;
+    issue(t * TB);
+    const uint32_t own = kTxt + threadIdx.x * LT::STRIDE + kBmHalo;  // LDS offset of the lane's own first byte
+    for (; t < t_end; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();
+        LT::park(txt, threadIdx.x, p0, THREADS);
+        LT::park(txt, THREADS + threadIdx.x, p1, THREADS);
+        LT::park(txt, 2 * THREADS + threadIdx.x, p2, THREADS);
+        LT::park(txt, 3 * THREADS + threadIdx.x, p3, THREADS);
+        if (threadIdx.x == 0) LT::park_front(txt, 0, ph);
+        __syncthreads();
+        if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
+        uint32_t x0 = 0, x1 = L;  // window ends [x0, x1) of the lane's segment are its own
+        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+        if (tile0 < e_begin || tile0 + TB > e_end) {  // (uniform) a tile at either end of the range
+            const uint64_t lo = seg > e_begin ? seg : e_begin;
+            const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+            x0 = lo < hi ? (uint32_t)(lo - seg) : 0u;
+            x1 = lo < hi ? (uint32_t)(hi - seg) : 0u;
+        }
+        bool parked = false;  // first candidate of this tile awaiting wave_verify
+        const uint8_t* parked_at = a.text;
+        uint32_t e = own + x0, k = 0, sh = 0;
+        const uint32_t ehi = own + x1;
+        while (e < ehi) {
+            const uint32_t c = smem[e - k];
+            const uint32_t pk = ptail[k];
+            const uint32_t t0 = bc[c];
+            sh = k == 0 ? t0 : sh;                 // hor.c:49: the shift is the window's LAST byte's
+            const bool eq = c == pk;               // hor.c:46
+            const bool full = eq && k == H;        // every byte the tile holds of the window is equal
+            bool ok = full;
+            if (LONG && __any(full)) {  // rare, wave-uniform: the rest of the window is in HBM
+                if (full) {
+                    const uint8_t* rest = a.text + seg + (e - own) - (m - 1);  // the window's first byte
+                    if (!parked) {
+                        parked = true;
+                        parked_at = rest;
+                        ok = false;  // counted by wave_verify below
+                    } else {
+                        ok = global_equal(rest, a.blob, m - 1 - H);
+                    }
+                }
+            }
+            hits += ok;
+            const bool on = eq && !full;
+            e += on ? 0u : sh;
+            k = on ? k + 1 : 0u;
+        }
+        if (LONG) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
+    }
+    flush_hits(hits, a.count, smem);
+}
+
 template <int THREADS, int L, bool LONG, int VAR>  // LONG: m-1 > back halo, windows are completed in HBM
 __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a1, uint64_t tile_first,
                                                     uint32_t ntiles, const BatchItem* __restrict__ batch)
@@ -326,6 +416,10 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a1, uint64_t tile_f
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if constexpr (VAR == 9) {
+        hor_flat<THREADS, L, LONG>(a, tile_first, ntiles, smem);
+        return;
+    }
     const uint32_t m = a.m, H = a.halo, H16 = round16(H);
     uint16_t* tab = reinterpret_cast<uint16_t*>(smem);
     uint8_t* ptail = smem + 512;                 // ptail[H-k] == P[m-1-k]
@@ -2580,6 +2674,12 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
                 return launch_tiled(hor_scan_bp<false>, a, tr, kBpThreads, lds, 5, num_cus, stream);
             }
 #endif
+            if (!a.sparse && m >= 2 && g_tune[2] != 3) {  // windows survive: the flat form, two-wave workgroups as bm_scan (tune(2,3): round 2's loop)
+                const size_t flds = 512 + 32 + LaneTile<kBmHalo>::bytes(kBmBusyT);
+                const TileRange ftr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kBmBusyT * kHorL);
+                if (m - 1 > H) return launch_tiled(hor_scan<kBmBusyT, kHorL, true, 9>, a, ftr, kBmBusyT, flds, 12, num_cus, stream);
+                return launch_tiled(hor_scan<kBmBusyT, kHorL, false, 9>, a, ftr, kBmBusyT, flds, 12, num_cus, stream);
+            }
             const size_t lds = 512 + r16(H + 1) + ((r16(H) + (size_t)kHorT * kHorL + 16 + 63) & ~(size_t)63);  // whole 64-byte blocks: tile_at() permutes inside them
             const TileRange tr = tiles_for(a.s_begin + m - 1, a.s_end + m - 1, (uint64_t)kHorT * kHorL);
             if (m - 1 > H) return launch_tiled(hor_scan<kHorT, kHorL, true, 0>, a, tr, kHorT, lds, tile_wgs(a), num_cus, stream);

@@ -232,17 +232,23 @@ def test_kernel_choice_follows_the_pattern(oracle):
     # short patterns (crossovers per algorithm): the Shift-Or runs kernel (round 1: the packed matcher)
     assert kf("hor", rnd[:7]) == "so_runs" and kf("hor", rnd[100:108]) in ("hor_scan", "so_runs")
     assert kf("bm", rnd[:7]) == "so_runs" and kf("bndm", rnd[:10]) == "so_runs" and kf("kr", rnd[:15]) == "so_runs" and kf("sbndm", rnd[:10]) == "so_runs"
-    # natural language, DNA-like alphabets: symbols repeat -> the Shift-Or runs kernel at any m (round 1: packed matcher)
+    # natural language, DNA-like alphabets: symbols repeat -> the Shift-Or runs kernel at any m (round 1: packed matcher) —
+    # except, since round 3, where the algorithm's own kernel holds on such patterns: the flat loops of bm_scan and
+    # hor_scan on natural language from 8 bytes on (not on a few symbols), bndm_scan with q-grams from 16 bytes on (two
+    # symbols: from 32)
     for m in (16, 64, 1024):
         for a in ("hor", "bm", "bndm", "qs", "raita", "hash3", "sbndm", "bndml", "tunedbm"):
-            assert kf(a, eng[200:200 + m]) == "so_runs", (a, m)
-            assert kf(a, four[:m]) == "so_runs", (a, m)
+            own_eng = {"bm": "bm_scan", "hor": "hor_scan", "tunedbm": "hor_scan", "bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs"}.get(a, "so_runs")
+            own_four = {"bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs"}.get(a, "so_runs")
+            assert kf(a, eng[200:200 + m]) == own_eng, (a, m)
+            assert kf(a, four[:m]) == own_four, (a, m)
+    assert kf("bm", eng[200:207]) == "so_runs" and kf("bm", eng[200:208]) == "bm_scan" and kf("bndm", eng[200:212]) == "so_runs" and kf("bndm", four[:12]) == "so_runs"
     assert kf("hor", b"abca") == "so_runs" and kf("bm", four[:4]) == "so_runs" and kf("hor", b"abcd") == "so_runs"
     # two symbols, 16+ bytes: the bit-parallel runs kernel, whatever the algorithm (KMP and KR keep their own, EPSM is
-    # the packed matcher except on patterns its first dword cannot tell apart)
+    # the packed matcher except on patterns its first dword cannot tell apart; BNDM its own from 32 bytes on)
     for m in (16, 33, 300):
         for a in engine.ALGOS:
-            want = {"kmp": "kmp_runs", "kr": "hor_scan_bp"}.get(a, "so_runs")
+            want = {"kmp": "kmp_runs", "kr": "hor_scan_bp", "bndm": "bndm_scan" if m >= 32 else "so_runs"}.get(a, "so_runs")
             assert kf(a, two[:m]) == want, (a, m)
     assert kf("hor", two[:12]) == "so_runs" and kf("epsm", two[:12]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"
     # ... and, since so_runs runs at 75-81 %, on four: EPSM from 8 bytes on (the skip algorithms are there by rule 1)

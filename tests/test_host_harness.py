@@ -115,9 +115,11 @@ def test_smart_gpus_rehearsal_on_one_box(tmp_path):
     host.  The harness path, its shard arithmetic and its report columns run; the times mean nothing."""
     r = run("smart", "-text", "rand4", "-plen", "2", "64", "-pset", "4", "-occ", "-seed", "7", "-tb", "60000", "-gpus", "3", "-algo", "hor,bm,kmp,so,bndm,epsm",
             cwd=str(tmp_path), env={"SMARTGPU_REDUCE_HOST": "1"})
+    single = tmp_path / "single"  # its own directory: both runs may get the same EXP<time> code and write the same files
+    single.mkdir()
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Text sharded over 3 GPUs" in r.stdout and "on the host (SMARTGPU_REDUCE_HOST: rehearsal)" in r.stdout
-    one = run("smart", "-text", "rand4", "-plen", "2", "64", "-pset", "4", "-occ", "-seed", "7", "-tb", "60000", "-algo", "hor,bm,kmp,so,bndm,epsm", cwd=str(tmp_path))
+    one = run("smart", "-text", "rand4", "-plen", "2", "64", "-pset", "4", "-occ", "-seed", "7", "-tb", "60000", "-algo", "hor,bm,kmp,so,bndm,epsm", cwd=str(single))
     assert one.returncode == 0, one.stdout + one.stderr
     rows = [ln for ln in r.stdout.splitlines() if "[OK]" in ln]
     assert len(rows) == 6 * 6 and all("% of 3 x 8 TB/s" in ln for ln in rows), r.stdout
