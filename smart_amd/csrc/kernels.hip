@@ -1729,7 +1729,7 @@ __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base,
 //             on its own made it slower: 0.218-0.232).
 template <bool PREFIX>  // PREFIX: m > 254 — the automaton of the 62-byte prefix; hits are verified
 __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
-                                                           uint32_t dfa_off, const BatchItem* __restrict__ batch)
+                                                           uint32_t dfa_off_in, const BatchItem* __restrict__ batch)
 {
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1747,6 +1747,8 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         pf.p1 = p << 24;
     }
     const uint32_t qbase = table_bytes;  // Q[s] = P[s..s+4) for the states kmp_chunk_skip4 covers (256 bytes)
+    const uint32_t p48 = *reinterpret_cast<const uint32_t*>(a.blob + 4);  // P[4..8) (the pattern slot is zero-padded)
+    const uint32_t dfa_off = dfa_off_in & 0x7FFFFFFFu;
     const uint32_t stored = (w < 63 ? w + 1 : 256u) * 256u;  // the blob's rows (tables.cpp kmp_runs_tables)
     const uint32_t thr = *reinterpret_cast<const uint32_t*>(a.blob + dfa_off + stored + 256);
     uint8_t* const slabs = smem + table_bytes + kKmpQBytes;
@@ -1800,6 +1802,12 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         // 8 lines.  The prefix automaton starts with form 2 (measured, above).
         const uint32_t mode0 = w < 5 ? 0u : !PREFIX ? 1u : thr >= 16u ? 2u : 0u;
         uint32_t mode = mode0;
+        // the speculative half: states 1..3 have no border, and the pattern's symbols do not repeat (a.sparse, api.cpp: random text
+        // over a large alphabet — on English the exceptions come every few halves and cost 6-12 % however the speculation was
+        // backed off; rand32, which a.sparse excludes, gained 9 % with one back-off policy and lost 5 % with another) (bit 31: off, tune(3,4))
+        const bool spec0 = thr >= 12u && a.sparse != 0 && (dfa_off_in >> 31) == 0;
+        bool spec_on = spec0;
+        uint32_t spec_fail = 0;
         bool dense = false;   // wave-uniform: many lanes saw an occurrence end in the last whole half
         bool parked = false;  // PREFIX: first unverified prefix hit of this step
         const uint8_t* parked_at = a.text;
@@ -1839,7 +1847,43 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
             };
             if (jb >= j0 && jb + 64u <= jend) {  // the whole half is inside the run
                 bool seen = false;
-                if (!dense) {
+                bool spec_done = false;
+                if (!dense && spec_on) {
+                    // Round 3, the SPECULATIVE half: four bytes x on from a state s <= 3 (none of which has a border) the
+                    // automaton is in kmp_fresh4(x) — unless x continues the match, x == P[s..s+4), or is P[0..4) itself.
+                    // On a large alphabet neither happens in a whole half of a whole wave (128^-4 per dword and lane), and
+                    // then the sixteen dwords do not depend on one another at all: sixteen independent kmp_fresh4, the
+                    // continuation tested against v_alignbyte_b32(P[4..8), P[0..4), s) with the SPECULATED previous state,
+                    // ONE ballot per half.  Any exception anywhere (which includes every occurrence: it passes through
+                    // state 4, K + 4 < w) sends the half through the forms below from its saved start state; the second
+                    // exception switches the speculation off for the rest of the wave's group of runs (natural language:
+                    // English m = 16 / 64 / 1024 measured 8-12 % SLOWER while it was re-armed every 8 lines).
+                    if (kmp_all_low(st, 12u)) {
+                        uint32_t prev = st;
+                        bool bad = false;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint4 v = run_piece(io, q);
+                            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const uint32_t cont = __builtin_amdgcn_alignbyte(p48, pf.p4, prev >> 2);  // P[s..s+4), s = prev / 4
+                                const uint32_t f = kmp_fresh4(d[k], pf);
+                                bad |= d[k] == cont || f == 16u;
+                                prev = f;
+                            }
+                        }
+                        if (!__any(bad)) {
+                            st = prev;
+                            spec_done = true;
+                        } else if (++spec_fail >= 2u) {
+                            spec_on = false;  // for the rest of this group of runs (natural language: " the" IS somebody's P[0..4))
+                        }
+                    }
+                }
+                if (spec_done) {
+                    // nothing: no lane left the states 0..3, no occurrence ended in this half
+                } else if (!dense) {
                     uint32_t at[4];  // state before each 16-byte chunk
                     if (mode == 1) {
                         bool low = __ballot(st != 0u) == 0;
@@ -2305,7 +2349,8 @@ bool tune_supported(int key, int value)
 #else
     switch (key) {
         case 0: return value == 0 || value == 1 || value == 3;  // 2: Horspool on the bank-private tiles
-        case 3: case 6: case 7: return value == 0;               // superseded KMP / SO kernels, packed load policies
+        case 3: return value == 0 || value == 4;                 // superseded KMP kernels (4: kmp_runs without its speculative half)
+        case 6: case 7: return value == 0;                       // superseded SO kernels, packed load policies
         default: return true;
     }
 #endif
@@ -2544,8 +2589,9 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     } else
 #endif
     {
-        if (m > kKmpWindow) SG_KMP_RUNS(kmp_runs<true>, dfa_off);
-        else SG_KMP_RUNS(kmp_runs<false>, dfa_off);
+        const uint32_t off3 = dfa_off | (g_tune[3] == 4 ? 0x80000000u : 0u);  // tune(3,4): without the speculative half (A/B)
+        if (m > kKmpWindow) SG_KMP_RUNS(kmp_runs<true>, off3);
+        else SG_KMP_RUNS(kmp_runs<false>, off3);
     }
 #undef SG_KMP_RUNS
     return hipGetLastError();
