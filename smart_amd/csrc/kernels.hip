@@ -1802,9 +1802,10 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         // 8 lines.  The prefix automaton starts with form 2 (measured, above).
         const uint32_t mode0 = w < 5 ? 0u : !PREFIX ? 1u : thr >= 16u ? 2u : 0u;
         uint32_t mode = mode0;
-        // the speculative half: states 1..3 have no border, and the pattern's symbols do not repeat (a.sparse, api.cpp: random text
-        // over a large alphabet — on English the exceptions come every few halves and cost 6-12 % however the speculation was
-        // backed off; rand32, which a.sparse excludes, gained 9 % with one back-off policy and lost 5 % with another) (bit 31: off, tune(3,4))
+        // the speculative half: states 1..3 have no border, and the pattern's symbols do not repeat (a.sparse, api.cpp build_blob:
+        // random text over a large alphabet).  On English the exceptions come every few halves and cost 6-12 % however the
+        // speculation was backed off; on rand32 (a.sparse says no) it measured +5 / +1 / -2 % at m = 16 / 64 / 1024.
+        // (bit 31: off, tune(3,4))
         const bool spec0 = thr >= 12u && a.sparse != 0 && (dfa_off_in >> 31) == 0;
         bool spec_on = spec0;
         uint32_t spec_fail = 0;
