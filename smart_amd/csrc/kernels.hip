@@ -211,12 +211,12 @@ static __device__ __forceinline__ void tile_park(uint8_t* txt, uint32_t i0, cons
     blk[(d + 3) ^ s] = v.w;
 }
 
-// Lane tiles (bm_scan, bndm_scan): the 64 text bytes a lane owns sit CONTIGUOUSLY in LDS behind a private copy of
+// Lane tiles (bm_scan, hor_flat): the 64 text bytes a lane owns sit CONTIGUOUSLY in LDS behind a private copy of
 // the DUP = HALO - 4 bytes before them, HALO + 64 bytes per lane — an odd number of dwords, so lanes at equal
 // offsets (a streaming scan on a large alphabet moves them in lockstep) cover all 32 banks without a swizzle.
 //   * the address of T[e - k] is one subtraction from the lane's cursor (tile_at: four VALU ops per read);
-//   * bytes are contiguous, so a q-gram is ONE unaligned ds_read_b32 / _b64 (gfx950 reads LDS at any byte address),
-//     not q byte reads through the swizzle;
+//   * bytes are contiguous (a q-gram could be ONE unaligned ds_read_b32 / _b64 — bndm_scan tried: the LDS stalls on them,
+//     see ColTile);
 //   * the price: the last DUP bytes of every segment are parked twice (16 more ds_write_b32 per tile in a quarter or
 //     half of the lanes) and a tile takes (64 + HALO) / 64 of its size in LDS.
 // Byte x (0..63) of segment s is at s * STRIDE + HALO + x; bytes [4, HALO) of a segment's region are T[seg - DUP, seg),
@@ -989,16 +989,14 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
 }
 
 // ---------------------------------------------------------------------------
-// Simplified BNDM (sbndm.c:28-149) on round 2's BNDM tiles — flat, dword-swizzled, a nested loop per window (bndm_scan
-// above is BNDM's kernel now; the SIMPLE = false path below is what it replaced and is not instantiated).
+// Simplified BNDM (sbndm.c:28-149) on round 2's BNDM tiles — flat, dword-swizzled, a nested loop per window (BNDM
+// itself moved to bndm_scan above in round 3).  No bookkeeping of the longest prefix seen: a window that dies after k
+// more bytes moves past the failing byte (shift w-k), an occurrence moves by the period of the (32-byte prefix of the)
+// pattern, which the host stores after the fingerprint.
 // w = min(m,32); tiles are indexed by the END of the w-byte (prefix) window.
 // LDS: u32 B[256] | text [tile0-32, tile0+TB)
 // ---------------------------------------------------------------------------
-// SIMPLE = true: Simplified BNDM (sbndm.c:28-149) on the same tiles and masks: no bookkeeping of the
-// longest prefix seen — a window that dies after k more bytes moves past the failing byte (shift
-// w-k), an occurrence moves by the period of the (prefix of the) pattern, which the host stores
-// after the fingerprint.
-template <int THREADS, int L, bool LONG, bool SIMPLE>  // LONG: m > 32, prefix hits are verified
+template <int THREADS, int L, bool LONG>  // LONG: m > 32, prefix hits are verified
 __global__ __launch_bounds__(THREADS) void sbndm_scan(ScanArgs a1, uint64_t tile_first,
                                                      uint32_t ntiles, const BatchItem* __restrict__ batch)
 {
@@ -1015,7 +1013,7 @@ __global__ __launch_bounds__(THREADS) void sbndm_scan(ScanArgs a1, uint64_t tile
     for (uint32_t i = threadIdx.x; i < 256; i += THREADS)
         B[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] << (32 - w);
 
-    const uint32_t period = SIMPLE ? *reinterpret_cast<const uint32_t*>(a.blob + kTableOff + 1024 + 32) : 0u;
+    const uint32_t period = *reinterpret_cast<const uint32_t*>(a.blob + kTableOff + 1024 + 32);
     const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
     uint32_t hits = 0;
     static_assert(TB == THREADS * 64, "prefetch registers are written out for L = 64");
@@ -1060,51 +1058,19 @@ __global__ __launch_bounds__(THREADS) void sbndm_scan(ScanArgs a1, uint64_t tile
                 if (D == 0) {
                     // sbndm.c:60-63 reads a second byte before it tests D and so moves by w-1
                     // here; its long-pattern form skips by w like BNDM (sbndm.c:133)
-                    e += (SIMPLE && !LONG) ? w - 1 : w;
+                    e += !LONG ? w - 1 : w;
                     continue;
                 }
-                if (SIMPLE) {
-                    uint32_t k = 1;
-                    for (;;) {  // sbndm.c:61-65
-                        D = (D << 1) & B[txt[tile_at(e - k)]];
-                        if (k == w - 1 || D == 0) break;
-                        ++k;
-                    }
-                    if (D != 0) {  // the whole window matched
-                        if (!LONG) {
-                            ++hits;
-                        } else {
-                            const uint8_t* rest = a.text + tile0 + (e - H16) + 1;  // = text + s + w
-                            if (!parked) {
-                                parked = true;
-                                parked_at = rest;
-                            } else {
-                                hits += global_equal(rest, a.blob + w, m - w);
-                            }
-                        }
-                        e += period;
-                    } else {
-                        e += w - k;
-                    }
-                    continue;
-                }
-                // bndm.c:49-58: D != 0 <=> the k bytes read so far are a factor of P[0..w); its top bit
-                // <=> they are a PREFIX of it, and the window may only move up to the longest such one.
-                // The loop is kept as small as Simplified BNDM's: an occurrence is handled after it.
-                uint32_t last = w, k = 1;
-                for (;;) {
-                    if ((int32_t)D < 0 && k < w) last = w - k;
-                    if (k == w) break;  // the whole window is read and D != 0: an occurrence
+                uint32_t k = 1;
+                for (;;) {  // sbndm.c:61-65
                     D = (D << 1) & B[txt[tile_at(e - k)]];
-                    if (D == 0) break;
+                    if (k == w - 1 || D == 0) break;
                     ++k;
                 }
-                if (D != 0) {
+                if (D != 0) {  // the whole window matched
                     if (!LONG) {
                         ++hits;
                     } else {
-                        // prefix of 32 matched: verify P[32..m) (bndm.c:99-102),
-                        // the window is inside the text because s < s_end
                         const uint8_t* rest = a.text + tile0 + (e - H16) + 1;  // = text + s + w
                         if (!parked) {
                             parked = true;
@@ -1113,8 +1079,10 @@ __global__ __launch_bounds__(THREADS) void sbndm_scan(ScanArgs a1, uint64_t tile
                             hits += global_equal(rest, a.blob + w, m - w);
                         }
                     }
+                    e += period;
+                } else {
+                    e += w - k;
                 }
-                e += last;
             }
         }
         if (LONG) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
@@ -2818,8 +2786,8 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
             if (algo == SMARTGPU_SBNDM) {
                 const size_t lds = 1024 + ((32 + (size_t)kBndmT * kBndmL + 63) & ~(size_t)63);  // whole 64-byte blocks (tile_at)
                 const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
-                if (m > 32) return launch_tiled(sbndm_scan<kBndmT, kBndmL, true, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
-                return launch_tiled(sbndm_scan<kBndmT, kBndmL, false, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
+                if (m > 32) return launch_tiled(sbndm_scan<kBndmT, kBndmL, true>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
+                return launch_tiled(sbndm_scan<kBndmT, kBndmL, false>, a, tr, kBndmT, lds, tile_wgs(a), num_cus, stream);
             }
             // BNDM (and BNDML's m <= 32): q bytes of a window per iteration, q = a.halo from the plan (api.cpp build_blob).
             // Workgroups per CU (26.6 KB of LDS each, six fit), measured on 1 GiB (ms): a streaming scan (a.sparse,

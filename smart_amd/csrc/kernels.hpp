@@ -16,7 +16,6 @@ namespace sg {
 constexpr uint64_t kFrontPad = 4608;            // >= kXSize + 256, multiple of 256
 constexpr uint64_t kBackPad = 160 * 1024;       // >= largest tile + kXSize + 64
 constexpr uint32_t kBmHalo = 20;                // bm_scan's lane tiles: 16 bytes of the previous segment + 4 of padding per lane
-constexpr uint32_t kBndmHalo = 36;              // bndm_scan's lane tiles: 32 bytes of the previous segment + 4 of padding per lane
 constexpr uint32_t kHaloMax = 16;               // bytes a lane verifies by itself in LDS before it parks the window
 constexpr uint32_t kPatternBytes = 4224;        // pattern slot in the plan blob (>= kXSize, /16)
 constexpr int kResultSlots = 4096;

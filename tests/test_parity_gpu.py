@@ -613,3 +613,35 @@ def test_pattern_set_larger_than_one_grid(oracle):
     with pytest.raises(smart_amd.engine.SmartGpuError):
         smart_amd.search_batch("hor", [pats[0]] * ((1 << 18) + 1), text, per_pattern_times=False)
     text.free()
+
+
+def test_kmp_speculative_halves(oracle):
+    """kmp_runs on a large alphabet speculates whole 64-byte halves (sixteen independent four-byte steps, one ballot): the
+    exceptions — an occurrence, P[0..4) alone, a match that continues across a dword — must send the half through the
+    ordinary forms.  Texts with all of them planted, against the oracle, with the speculation on and off (tune(3,4))."""
+    from smart_amd import engine
+    rng = np.random.default_rng(5)
+    n = 3 << 20
+    for m in (9, 16, 33, 62, 63, 254, 300):
+        T = oracle.gen_text(4242 + m, 128, 0, n)
+        P = T[100_000:100_000 + m].copy()
+        assert smart_amd.kernel_for("kmp", P) == "kmp_runs"
+        for k in rng.integers(0, n - m, 200):          # whole occurrences, anywhere (any half / line / run boundary)
+            T[k:k + m] = P
+        for k in rng.integers(0, n - 8, 2000):         # P[0..4) alone, and prefixes of 5..8 bytes that then break off
+            j = int(rng.integers(4, 9))
+            T[k:k + j] = P[:j]
+        T[n - m:] = P                                    # an occurrence at the very end
+        text = Text.upload(T)
+        want = oracle.search("kmp", P, T)
+        assert want >= 100
+        got_on = smart_amd.search("kmp", P, text)[0]
+        engine.tune(3, 4)
+        try:
+            got_off = smart_amd.search("kmp", P, text)[0]
+        finally:
+            engine.tune(3, 0)
+        assert got_on == want and got_off == want, (m, got_on, got_off, want)
+        sub = smart_amd.search("kmp", P, text, off=123_457, n=1_500_001)[0]
+        assert sub == oracle.search("kmp", P, T[123_457:123_457 + 1_500_001]), m
+        text.free()
