@@ -229,7 +229,8 @@ int smartgpu_probe_read_ms(const smartgpu_text *t, int reps, double *ms_per_pass
  *   2  bm_scan / bndm_scan workgroups: 1 four waves / 2 two waves (0 = default: bm_scan two where the pattern's symbols
  *      repeat, bndm_scan always four)
  *   3  KMP: 0 kmp_runs (transition table) / 1 kmp_scan (LDS tiles, m <= 40) / 2 kmp_links_runs
- *      (failure links followed per byte) / 4 kmp_runs without its speculative halves (round 3)
+ *      (failure links followed per byte) / 4 kmp_runs without its speculative halves / 5 without its
+ *      four-bytes-per-step table (round 3)
  *   5  run length in bytes of the runs kernels (so_runs, kmp_runs); 0 = default
  *   6  SO: 0 so_runs (bank-private table, line fetch) / 1 so_scan (LDS tiles) / 2 so_runs64
  *      (shared table, 64-byte steps); SA: 3 = its own AND form (default: the complemented, Shift-Or form)
@@ -247,6 +248,9 @@ int smartgpu_tune(int key, int value);
  *            expanded into delta[state][byte]; state m = an occurrence ends here
  *          6 the same over the pattern's own alphabet: k1, colmap[256], table[(m+1)*k1]
  *          7 Shift-And masks S[256] (sa.c:27-34), 8 Quick Search shifts qsBc[256] (qs.c:27-31),
+ *          9 kmp_runs' tables as the kernel holds them in LDS (bytes; the last 272: Q and thr),
+ *          10 kmp_runs' four-bytes-per-step table for patterns over at most four symbols:
+ *            (w+1)*256 entries (w = min(m, 62)), then shift and symtab; 0 entries when the pattern does not qualify,
  *          13/15/18 HASH3/5/8 shifts[256] followed by the shift after a candidate (hash3.c:36-56)   */
 int smartgpu_build_table(int which, const uint8_t *P, uint32_t m, int32_t *out, uint32_t cap);
 

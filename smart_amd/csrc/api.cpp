@@ -277,7 +277,17 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
             // kmp_runs: the automaton over w = kmp_window(m) bytes (the pattern, or its 62-byte prefix beyond 254) with an ABSORBING accept row Z (every transition into
             // the accept state w leads to Z, Z leads to Z; row id(w) holds the real delta(w, .)), and the table of the
             // four-bytes-at-a-time forms (tables.cpp)
-            sg::kmp_runs_tables(P, sg::kmp_window(m), blob);
+            // ... over at most four symbols (DNA-like alphabets): a second table that takes FOUR text bytes per step
+            // (tables.cpp kmp_four_tables) — the window is then the pattern or its 62-byte prefix (the table lives in the gaps
+            // of the byte table, whose ids are 4s up to 62 states); its length travels as the plan's prefer_packed field
+            std::vector<uint8_t> four;
+            const uint32_t w4 = std::min<uint32_t>(m, sg::kKmpPrefix);
+            const bool has4 = m >= 2 && sg::kmp_four_tables(P, w4, four);
+            sg::kmp_runs_tables(P, has4 ? w4 : sg::kmp_window(m), blob);
+            if (has4) {
+                append(four.data(), four.size());
+                *prefer_packed = w4;
+            }
 #ifdef SMARTGPU_AB
             {   // kmp_runs1 (A/B build): the automaton of P[0..w), w = min(m, 255); state s is row id(s) = rotl8(s, 2),
                 // the accept state row 255 — or row 4w while the ids 4s do not wrap (w < 64) —, the largest id (its
@@ -1382,6 +1392,18 @@ int smartgpu_build_table(int which, const uint8_t* P, uint32_t m, int32_t* out, 
                 t.swap(lds);
             }
             v.assign(t.begin(), t.end());
+            break;
+        }
+        case 10: {  // kmp_runs' four-bytes-per-step table: (w+1)*256 entries, then shift, symtab (w = min(m, 62)); no entries: not applicable
+            std::vector<uint8_t> t;
+            const uint32_t w = std::min<uint32_t>(m, sg::kKmpPrefix);
+            if (sg::kmp_four_tables(P, w, t)) {
+                v.assign(t.begin(), t.begin() + (w + 1) * 256);
+                uint32_t par[2];
+                std::memcpy(par, t.data() + (w + 1) * 256, 8);
+                v.push_back(static_cast<int32_t>(par[0]));
+                v.push_back(static_cast<int32_t>(par[1]));
+            }
             break;
         }
         case 8: v = sg::quick_search_shifts(P, m); break;

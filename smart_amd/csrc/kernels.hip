@@ -1665,6 +1665,35 @@ __device__ __forceinline__ void kmp_chunk_skip4(const uint4& v, uint32_t& st, bo
     }
 }
 
+// Sixteen transitions as FOUR table steps of four bytes each (patterns over at most four symbols, tables.cpp
+// kmp_four_tables): the codes (c >> shift) & 3 of a dword's bytes make the index, one v_perm_b32 rebuilds the dword
+// from the symbols of those codes — equal <=> every byte IS one of the pattern's symbols —, and the step is one lookup
+// in row id + 2 (the gaps of the byte table).  Index and check do not depend on the state: only v_or, v_lshl_or, v_xor
+// and the LDS read are on the chain, once per four bytes.  A chunk in which any lane holds any other byte takes the
+// sixteen byte steps.
+__device__ __forceinline__ void kmp_chunk_four(const uint4& v, uint32_t& st, uint32_t shift, uint32_t symtab)
+{
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+    uint32_t idx[4];
+    bool valid = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t c = (d[k] >> shift) & 0x03030303u;
+        valid = valid && __builtin_amdgcn_perm(symtab, symtab, c) == d[k];
+        const uint32_t t = c | (c >> 6);
+        idx[k] = (t | (t >> 12)) & 0xFFu;  // the first byte's code in bits 0-1, ... the fourth's in bits 6-7
+    }
+    if (__ballot(!valid) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t r = st | 2u;  // ids are 4s here: row 4s + 2
+            st = *(const lds_u8_t*)(size_t)(((r << 8) | idx[k]) ^ r);
+        }
+    } else {
+        kmp_chunk_fast(v, st);
+    }
+}
+
 // sixteen transitions, counting (MASK: collecting) the entries into Z; CHECK: only bytes j0 <= j < jend
 template <bool CHECK, bool MASK>
 __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
@@ -1705,7 +1734,10 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t w = PREFIX ? kKmpPrefix : m;  // length the automaton recognises
     const uint32_t idw = w < 63 ? 4 * w : 254u, Z = idw + 1;
-    const uint32_t table_bytes = (Z + 1) * 256;
+    // the plan carries the four-bytes-per-step table (api.cpp build_blob; w < 63 then) (bit 30 of the argument: do not use it, tune(3,5))
+    const bool four = a.prefer_packed != 0 && (dfa_off_in & 0x40000000u) == 0;
+    // (+ two rows of that table: 4w + 2, the accept state's, and 4w + 3 = Z | 2, all Z: a lane that fell into Z stays there)
+    const uint32_t table_bytes = (Z + 1 + (four ? 2u : 0u)) * 256;
     KmpPrefix4 pf;
     {
         const uint32_t p = *reinterpret_cast<const uint32_t*>(a.blob);  // P[0..4) (the pattern slot is zero-padded)
@@ -1716,9 +1748,12 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     }
     const uint32_t qbase = table_bytes;  // Q[s] = P[s..s+4) for the states kmp_chunk_skip4 covers (256 bytes)
     const uint32_t p48 = *reinterpret_cast<const uint32_t*>(a.blob + 4);  // P[4..8) (the pattern slot is zero-padded)
-    const uint32_t dfa_off = dfa_off_in & 0x7FFFFFFFu;
+    const uint32_t dfa_off = dfa_off_in & 0x3FFFFFFFu;
     const uint32_t stored = (w < 63 ? w + 1 : 256u) * 256u;  // the blob's rows (tables.cpp kmp_runs_tables)
     const uint32_t thr = *reinterpret_cast<const uint32_t*>(a.blob + dfa_off + stored + 256);
+    const uint8_t* const blob4 = a.blob + dfa_off + stored + kKmpQBytes;  // the rows of the four-byte table, then shift and symtab
+    const uint32_t shift4 = four ? *reinterpret_cast<const uint32_t*>(blob4 + (w + 1) * 256u) : 0u;
+    const uint32_t symtab4 = four ? *reinterpret_cast<const uint32_t*>(blob4 + (w + 1) * 256u + 4) : 0u;
     uint8_t* const slabs = smem + table_bytes + kKmpQBytes;
     const RunIo io = swap_io(slabs + wave * kLineSlab, lane, run_len);
     {
@@ -1731,6 +1766,11 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
             const uint32_t z4 = Z * 0x01010101u;
             if (threadIdx.x < 16) t[Z * 16 + threadIdx.x] = make_uint4(z4, z4, z4, z4);
             else if (threadIdx.x < 32) t[table_bytes / 16 + threadIdx.x - 16] = g[stored / 16 + threadIdx.x - 16];
+            if (four) {  // row s of the four-byte table goes to row 4s + 2
+                const uint4* g4 = reinterpret_cast<const uint4*>(blob4);
+                for (uint32_t i = threadIdx.x; i < (w + 1) * 16; i += kRunWaves * 64) t[((i >> 4) * 4 + 2) * 16 + (i & 15u)] = g4[i];
+                if (threadIdx.x >= 32 && threadIdx.x < 48) t[(Z + 2) * 16 + threadIdx.x - 32] = make_uint4(z4, z4, z4, z4);
+            }
         } else {
             for (uint32_t i = threadIdx.x; i < (table_bytes + 256) / 16; i += kRunWaves * 64) t[i] = g[i];
         }
@@ -1768,7 +1808,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         // dword; natural language, medium alphabets — not worth trying with K < 4), 0: a lookup per byte.  A half in
         // which a form covered fewer than 6 of the 16 dwords hands over to the next one; tried again from the top every
         // 8 lines.  The prefix automaton starts with form 2 (measured, above).
-        const uint32_t mode0 = w < 5 ? 0u : !PREFIX ? 1u : thr >= 16u ? 2u : 0u;
+        const uint32_t mode0 = four ? 5u : w < 5 ? 0u : !PREFIX ? 1u : thr >= 16u ? 2u : 0u;
         uint32_t mode = mode0;
         // the speculative half: states 1..3 have no border, and the pattern's symbols do not repeat (a.sparse, api.cpp build_blob:
         // random text over a large alphabet).  On English the exceptions come every few halves and cost 6-12 % however the
@@ -1863,6 +1903,12 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
                             kmp_chunk_skip4<false>(run_piece(io, q), st, low, pf, qbase, 0u, nfast);
                         }
                         if (nfast < 6) mode = thr >= 16u ? 2u : 0u;
+                    } else if (mode == 5) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            at[q] = st;
+                            kmp_chunk_four(run_piece(io, q), st, shift4, symtab4);
+                        }
                     } else if (mode == 2) {
                         bool low = kmp_all_low(st, thr);
                         uint32_t nfast = 0;
@@ -2318,7 +2364,7 @@ bool tune_supported(int key, int value)
 #else
     switch (key) {
         case 0: return value == 0 || value == 1 || value == 3;  // 2: Horspool on the bank-private tiles
-        case 3: return value == 0 || value == 4;                 // superseded KMP kernels (4: kmp_runs without its speculative half)
+        case 3: return value == 0 || value == 4 || value == 5;   // superseded KMP kernels (4 / 5: kmp_runs without its speculative halves / four-byte table)
         case 6: case 7: return value == 0;                       // superseded SO kernels, packed load policies
         default: return true;
     }
@@ -2505,12 +2551,13 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
 {
     const uint32_t m = a.m;
     const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));  // the transition table of kmp_runs (api.cpp build_blob)
-    uint32_t w = kmp_window(m);                             // bytes the automaton recognises; a run re-scans w-1
-    const uint32_t rows = w < 63 ? 4 * w + 2 : 256;         // up to the absorbing row Z
+    const bool four = a.prefer_packed != 0 && g_tune[3] != 5;   // the plan carries the four-bytes-per-step table (tune(3,5): unused, A/B)
+    uint32_t w = a.prefer_packed ? a.prefer_packed : kmp_window(m);  // bytes the automaton recognises (with that table: api.cpp); a run re-scans w-1
+    const uint32_t rows = (w < 63 ? 4 * w + 2 : 256) + (four ? 2 : 0);  // up to the absorbing row Z (+ rows 4w+2, 4w+3 of the four-byte table)
 #ifdef SMARTGPU_AB
     const bool links = g_tune[3] == 2;  // failure links
     const bool v1 = g_tune[3] == 3;     // the previous kernel (running maximum, half-line loader): its table follows
-    const uint32_t dfa1_off = dfa_off + (w < 63 ? w + 1 : 256u) * 256 + kKmpQBytes;
+    const uint32_t dfa1_off = dfa_off + (w < 63 ? w + 1 : 256u) * 256 + kKmpQBytes + (a.prefer_packed ? (w + 1) * 256 + 16 : 0);
     if (links || v1) w = (links || m <= kKmpDfaMaxM) ? m : kKmpDfaMaxM;
     if (links) {
         const uint64_t span = a.s_end - a.s_begin;
@@ -2558,8 +2605,8 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     } else
 #endif
     {
-        const uint32_t off3 = dfa_off | (g_tune[3] == 4 ? 0x80000000u : 0u);  // tune(3,4): without the speculative half (A/B)
-        if (m > kKmpWindow) SG_KMP_RUNS(kmp_runs<true>, off3);
+        const uint32_t off3 = dfa_off | (g_tune[3] == 4 ? 0x80000000u : 0u) | (g_tune[3] == 5 ? 0x40000000u : 0u);  // tune(3,4): without the speculative halves, (3,5): without the four-byte table (A/B)
+        if (m > w) SG_KMP_RUNS(kmp_runs<true>, off3);  // beyond 254 bytes — or, with the four-byte table, beyond 62: the prefix's automaton
         else SG_KMP_RUNS(kmp_runs<false>, off3);
     }
 #undef SG_KMP_RUNS

@@ -419,8 +419,8 @@ def kernel_for(algo, P):
 def build_table(which, P):
     P = _u8(P)
     names = {"bad_char": 0, "good_suffix": 1, "kmp_next": 2, "shift_or": 3, "bndm": 4, "kmp_dfa": 5,
-             "kmp_dfa_compressed": 6, "shift_and": 7, "quick_search": 8, "kmp_runs": 9, "hash3": 13, "hash5": 15, "hash8": 18}
-    out = np.empty(max(257, len(P) + 1, (len(P) + 1) * 256 + 257 if which.startswith("kmp_dfa") else 256 * 256 + 272 if which == "kmp_runs" else 0), dtype=np.int32)
+             "kmp_dfa_compressed": 6, "shift_and": 7, "quick_search": 8, "kmp_runs": 9, "kmp_four": 10, "hash3": 13, "hash5": 15, "hash8": 18}
+    out = np.empty(max(257, len(P) + 1, (len(P) + 1) * 256 + 257 if which.startswith("kmp_dfa") else 256 * 256 + 272 if which in ("kmp_runs", "kmp_four") else 0), dtype=np.int32)
     k = lib().smartgpu_build_table(names[which], P.ctypes.data, len(P), out.ctypes.data, len(out))
     if k < 0:
         raise _err("build_table")

@@ -300,3 +300,42 @@ def test_product_library_carries_no_superseded_kernels():
     finally:
         engine.use_library()
     assert smart_amd.kernel_for("kmp", b"abcdabcdabcd") == "kmp_runs"
+
+
+def test_kmp_four_byte_table_is_four_steps_of_the_automaton(oracle):
+    """kmp_runs on patterns over at most four symbols: the table that takes FOUR text bytes per step (tables.cpp
+    kmp_four_tables) against four steps of the plain transition table (build_table "kmp_dfa"), for every state and every
+    index; entries that pass through the accept state say Z; a fifth symbol, or symbols whose two-bit codes collide at
+    every shift, disqualify the pattern."""
+    rng = np.random.default_rng(3)
+    pats = [np.frombuffer(b"ACGTACGTTGCAAC", dtype=np.uint8), rng.integers(0, 2, 16, dtype=np.uint8), rng.integers(0, 4, 62, dtype=np.uint8),
+            rng.integers(0, 4, 200, dtype=np.uint8), np.frombuffer(b"abababababab", dtype=np.uint8), np.frombuffer(b"aaaaaaaaa", dtype=np.uint8),
+            np.array([7, 7, 200, 7, 200, 200, 7, 33, 33], dtype=np.uint8)]
+    for P in pats:
+        got = smart_amd.build_table("kmp_four", P)
+        w = min(len(P), 62)
+        assert len(got) == (w + 1) * 256 + 2, len(P)
+        tab = got[:(w + 1) * 256].astype(np.uint8).reshape(w + 1, 256)
+        shift, symtab = int(got[-2]), int(got[-1]) & 0xFFFFFFFF
+        syms = sorted(set(P[:w].tolist()))
+        codes = {c: (c >> shift) & 3 for c in syms}
+        assert len(set(codes.values())) == len(syms)
+        sym_of = {v: k for k, v in codes.items()}
+        for c in range(4):  # symtab: the symbol of each code; an unused code's entry has another code
+            b = (symtab >> (8 * c)) & 0xFF
+            assert b == sym_of[c] if c in sym_of else ((b >> shift) & 3) != c
+        dfa = smart_amd.build_table("kmp_dfa", P[:w]).reshape(w + 1, 256)
+        Z = 4 * w + 1
+        for s in range(w + 1):
+            r = 4 * s + 2
+            for idx in range(256):
+                t, hit = s, False
+                for j in range(4):
+                    c = (idx >> (2 * j)) & 3
+                    t = int(dfa[t, sym_of[c]]) if c in sym_of else 0
+                    hit = hit or t == w
+                assert tab[s, (idx ^ r) & 255] == (Z if hit else 4 * t), (len(P), s, idx)
+    five = np.array([1, 2, 3, 4, 5, 1, 2, 3, 4], dtype=np.uint8)
+    assert len(smart_amd.build_table("kmp_four", five)) == 0
+    clash = np.array([0x00, 0x04, 0x10, 0x40, 0x00, 0x04, 0x10, 0x40, 0x04], dtype=np.uint8)  # any two bits of these tell at most three apart
+    assert len(smart_amd.build_table("kmp_four", clash)) == 0
