@@ -1665,28 +1665,6 @@ __device__ __forceinline__ void kmp_chunk_skip4(const uint4& v, uint32_t& st, bo
     }
 }
 
-// Sixteen transitions SPECULATED (natural language, medium alphabets: where a whole half rarely goes without an
-// exception but a 16-byte chunk of a wave does about every second time): as in the speculative half of kmp_runs, the
-// four dwords' kmp_fresh4 do not depend on one another and the continuation is tested against the speculated previous
-// state; returns false — st untouched — when any lane starts beyond state 3 or meets an exception, and the caller walks
-// the chunk with the form it would have used.
-__device__ __forceinline__ bool kmp_chunk_spec(const uint4& v, uint32_t& st, const KmpPrefix4& pf, uint32_t p48)
-{
-    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-    uint32_t prev = st;
-    bool bad = __builtin_amdgcn_alignbit(st, st, 2) > 3u;  // not one of the ids 0, 4, 8, 12
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t cont = __builtin_amdgcn_alignbyte(p48, pf.p4, prev >> 2);  // P[s..s+4), s = prev / 4
-        const uint32_t f = kmp_fresh4(d[k], pf);
-        bad |= d[k] == cont || f == 16u;
-        prev = f;
-    }
-    if (__ballot(bad) != 0) return false;
-    st = prev;
-    return true;
-}
-
 // Sixteen transitions as FOUR table steps of four bytes each (patterns over at most four symbols, tables.cpp
 // kmp_four_tables): the codes (c >> shift) & 3 of a dword's bytes make the index, one v_perm_b32 rebuilds the dword
 // from the symbols of those codes — equal <=> every byte IS one of the pattern's symbols —, and the step is one lookup
@@ -1837,11 +1815,6 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         // speculation was backed off; on rand32 (a.sparse says no) it measured +5 / +1 / -2 % at m = 16 / 64 / 1024.
         // (bit 31: off, tune(3,4))
         const bool spec0 = thr >= 12u && a.sparse != 0 && (dfa_off_in >> 31) == 0;
-        // ... and where they do repeat (natural language, medium alphabets) the same per 16-byte chunk inside form 2
-        // — while it pays: a speculated chunk costs ~48 VALU ops, the chain it saves ~450 clocks; below one success in two
-        // (a pattern that opens with a frequent four-gram, "d th") it is switched off for the wave's group of runs
-        bool chunk_spec = thr >= 12u && a.sparse == 0 && (dfa_off_in >> 31) == 0;
-        uint32_t cs_tried = 0, cs_won = 0;
         bool spec_on = spec0;
         uint32_t spec_fail = 0;
         bool dense = false;   // wave-uniform: many lanes saw an occurrence end in the last whole half
@@ -1942,33 +1915,14 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             at[q] = st;
-                            const uint4 piece = run_piece(io, q);
-                            if (chunk_spec) {
-                                ++cs_tried;
-                                if (kmp_chunk_spec(piece, st, pf, p48)) {  // (wave-uniform) the chunk went without an exception
-                                    ++cs_won;
-                                    nfast += 4;
-                                    low = true;
-                                    continue;
-                                }
-                                low = kmp_all_low(st, thr);
-                            }
-                            kmp_chunk_skip4<true>(piece, st, low, pf, qbase, thr, nfast);
+                            kmp_chunk_skip4<true>(run_piece(io, q), st, low, pf, qbase, thr, nfast);
                         }
                         if (nfast < 6) mode = 0u;
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             at[q] = st;
-                            const uint4 piece = run_piece(io, q);
-                            if (chunk_spec) {
-                                ++cs_tried;
-                                if (kmp_chunk_spec(piece, st, pf, p48)) {
-                                    ++cs_won;
-                                    continue;
-                                }
-                            }
-                            kmp_chunk_fast(piece, st);
+                            kmp_chunk_fast(run_piece(io, q), st);
                         }
                     }
                     seen = st == Z;
@@ -2003,10 +1957,6 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         };
         for (uint32_t k = 0; k < nlines; ++k) {
             if ((k & 7u) == 7u) mode = mode0;
-            if (cs_tried >= 8u) {  // (uniform) every line or two: is the chunk speculation paying?
-                if (2u * cs_won < cs_tried) chunk_spec = false;
-                cs_tried = cs_won = 0;
-            }
             SWAP_LINE();
             RUN_PARK(io, n0, n2, n4, n6);
             half(k * kRunLine);
