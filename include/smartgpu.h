@@ -229,8 +229,7 @@ int smartgpu_probe_read_ms(const smartgpu_text *t, int reps, double *ms_per_pass
  *   2  bm_scan / bndm_scan workgroups: 1 four waves / 2 two waves (0 = default: bm_scan two where the pattern's symbols
  *      repeat, bndm_scan always four)
  *   3  KMP: 0 kmp_runs (transition table) / 1 kmp_scan (LDS tiles, m <= 40) / 2 kmp_links_runs
- *      (failure links followed per byte) / 4 kmp_runs without its speculative halves / 5 without its
- *      four-bytes-per-step table (round 3)
+ *      (failure links followed per byte) / 5 kmp_runs without its four-bytes-per-step table (round 3)
  *   5  run length in bytes of the runs kernels (so_runs, kmp_runs); 0 = default
  *   6  SO: 0 so_runs (bank-private table, line fetch) / 1 so_scan (LDS tiles) / 2 so_runs64
  *      (shared table, 64-byte steps); SA: 3 = its own AND form (default: the complemented, Shift-Or form)

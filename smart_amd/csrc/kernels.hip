@@ -1724,9 +1724,13 @@ __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base,
 //   m = 64 .. 254 (full 64 KB table): half-line loader of kmp_runs1 0.206-0.210, swap 0.197-0.199, + forms 0.183-0.19;
 //   m > 254 (PREFIX): half-line 0.207-0.213, swap 0.206-0.212, swap + the 0..K form 0.196-0.199 (the state-0 form
 //             on its own made it slower: 0.218-0.232).
-template <bool PREFIX>  // PREFIX: m > 254 — the automaton of the 62-byte prefix; hits are verified
+// FOUR — a separate INSTANTIATION, so that what it needs costs round 2's kernel nothing (as a run-time switch, together
+// with a speculation for large alphabets that was dropped, it cost the English and rand32 cells 4-11 % against round 2's
+// build: 124 VGPRs, a larger loop): the plan carries the four-bytes-per-step table (patterns over at most four symbols,
+// api.cpp build_blob; the window is then at most 62 bytes)
+template <bool PREFIX, bool FOUR>  // PREFIX: the automaton of the 62-byte prefix (m > 254; FOUR: m > 62); hits are verified
 __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
-                                                           uint32_t dfa_off_in, const BatchItem* __restrict__ batch)
+                                                           uint32_t dfa_off, const BatchItem* __restrict__ batch)
 {
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1734,8 +1738,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t w = PREFIX ? kKmpPrefix : m;  // length the automaton recognises
     const uint32_t idw = w < 63 ? 4 * w : 254u, Z = idw + 1;
-    // the plan carries the four-bytes-per-step table (api.cpp build_blob; w < 63 then) (bit 30 of the argument: do not use it, tune(3,5))
-    const bool four = a.prefer_packed != 0 && (dfa_off_in & 0x40000000u) == 0;
+    constexpr bool four = FOUR;
     // (+ two rows of that table: 4w + 2, the accept state's, and 4w + 3 = Z | 2, all Z: a lane that fell into Z stays there)
     const uint32_t table_bytes = (Z + 1 + (four ? 2u : 0u)) * 256;
     KmpPrefix4 pf;
@@ -1747,8 +1750,6 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         pf.p1 = p << 24;
     }
     const uint32_t qbase = table_bytes;  // Q[s] = P[s..s+4) for the states kmp_chunk_skip4 covers (256 bytes)
-    const uint32_t p48 = *reinterpret_cast<const uint32_t*>(a.blob + 4);  // P[4..8) (the pattern slot is zero-padded)
-    const uint32_t dfa_off = dfa_off_in & 0x3FFFFFFFu;
     const uint32_t stored = (w < 63 ? w + 1 : 256u) * 256u;  // the blob's rows (tables.cpp kmp_runs_tables)
     const uint32_t thr = *reinterpret_cast<const uint32_t*>(a.blob + dfa_off + stored + 256);
     const uint8_t* const blob4 = a.blob + dfa_off + stored + kKmpQBytes;  // the rows of the four-byte table, then shift and symtab
@@ -1810,13 +1811,6 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         // 8 lines.  The prefix automaton starts with form 2 (measured, above).
         const uint32_t mode0 = four ? 5u : w < 5 ? 0u : !PREFIX ? 1u : thr >= 16u ? 2u : 0u;
         uint32_t mode = mode0;
-        // the speculative half: states 1..3 have no border, and the pattern's symbols do not repeat (a.sparse, api.cpp build_blob:
-        // random text over a large alphabet).  On English the exceptions come every few halves and cost 6-12 % however the
-        // speculation was backed off; on rand32 (a.sparse says no) it measured +5 / +1 / -2 % at m = 16 / 64 / 1024.
-        // (bit 31: off, tune(3,4))
-        const bool spec0 = thr >= 12u && a.sparse != 0 && (dfa_off_in >> 31) == 0;
-        bool spec_on = spec0;
-        uint32_t spec_fail = 0;
         bool dense = false;   // wave-uniform: many lanes saw an occurrence end in the last whole half
         bool parked = false;  // PREFIX: first unverified prefix hit of this step
         const uint8_t* parked_at = a.text;
@@ -1856,43 +1850,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
             };
             if (jb >= j0 && jb + 64u <= jend) {  // the whole half is inside the run
                 bool seen = false;
-                bool spec_done = false;
-                if (!dense && spec_on) {
-                    // Round 3, the SPECULATIVE half: four bytes x on from a state s <= 3 (none of which has a border) the
-                    // automaton is in kmp_fresh4(x) — unless x continues the match, x == P[s..s+4), or is P[0..4) itself.
-                    // On a large alphabet neither happens in a whole half of a whole wave (128^-4 per dword and lane), and
-                    // then the sixteen dwords do not depend on one another at all: sixteen independent kmp_fresh4, the
-                    // continuation tested against v_alignbyte_b32(P[4..8), P[0..4), s) with the SPECULATED previous state,
-                    // ONE ballot per half.  Any exception anywhere (which includes every occurrence: it passes through
-                    // state 4, K + 4 < w) sends the half through the forms below from its saved start state; the second
-                    // exception switches the speculation off for the rest of the wave's group of runs (natural language:
-                    // English m = 16 / 64 / 1024 measured 8-12 % SLOWER while it was re-armed every 8 lines).
-                    if (kmp_all_low(st, 12u)) {
-                        uint32_t prev = st;
-                        bool bad = false;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const uint4 v = run_piece(io, q);
-                            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const uint32_t cont = __builtin_amdgcn_alignbyte(p48, pf.p4, prev >> 2);  // P[s..s+4), s = prev / 4
-                                const uint32_t f = kmp_fresh4(d[k], pf);
-                                bad |= d[k] == cont || f == 16u;
-                                prev = f;
-                            }
-                        }
-                        if (!__any(bad)) {
-                            st = prev;
-                            spec_done = true;
-                        } else if (++spec_fail >= 2u) {
-                            spec_on = false;  // for the rest of this group of runs (natural language: " the" IS somebody's P[0..4))
-                        }
-                    }
-                }
-                if (spec_done) {
-                    // nothing: no lane left the states 0..3, no occurrence ended in this half
-                } else if (!dense) {
+                if (!dense) {
                     uint32_t at[4];  // state before each 16-byte chunk
                     if (mode == 1) {
                         bool low = __ballot(st != 0u) == 0;
@@ -1903,7 +1861,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
                             kmp_chunk_skip4<false>(run_piece(io, q), st, low, pf, qbase, 0u, nfast);
                         }
                         if (nfast < 6) mode = thr >= 16u ? 2u : 0u;
-                    } else if (mode == 5) {
+                    } else if (FOUR && mode == 5) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             at[q] = st;
@@ -2364,7 +2322,7 @@ bool tune_supported(int key, int value)
 #else
     switch (key) {
         case 0: return value == 0 || value == 1 || value == 3;  // 2: Horspool on the bank-private tiles
-        case 3: return value == 0 || value == 4 || value == 5;   // superseded KMP kernels (4 / 5: kmp_runs without its speculative halves / four-byte table)
+        case 3: return value == 0 || value == 5;                 // superseded KMP kernels (5: kmp_runs without its four-byte table)
         case 6: case 7: return value == 0;                       // superseded SO kernels, packed load policies
         default: return true;
     }
@@ -2605,9 +2563,14 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     } else
 #endif
     {
-        const uint32_t off3 = dfa_off | (g_tune[3] == 4 ? 0x80000000u : 0u) | (g_tune[3] == 5 ? 0x40000000u : 0u);  // tune(3,4): without the speculative halves, (3,5): without the four-byte table (A/B)
-        if (m > w) SG_KMP_RUNS(kmp_runs<true>, off3);  // beyond 254 bytes — or, with the four-byte table, beyond 62: the prefix's automaton
-        else SG_KMP_RUNS(kmp_runs<false>, off3);
+        // tune(3,5): without the four-byte table — round 2's kernel on the same tables (A/B)
+        if (four) {
+            if (m > w) SG_KMP_RUNS((kmp_runs<true, true>), dfa_off);  // beyond 62 bytes: the prefix's automaton
+            else SG_KMP_RUNS((kmp_runs<false, true>), dfa_off);
+        } else {
+            if (m > w) SG_KMP_RUNS((kmp_runs<true, false>), dfa_off);  // beyond 254 bytes (62 with the four-byte table's window)
+            else SG_KMP_RUNS((kmp_runs<false, false>), dfa_off);
+        }
     }
 #undef SG_KMP_RUNS
     return hipGetLastError();

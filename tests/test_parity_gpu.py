@@ -615,33 +615,38 @@ def test_pattern_set_larger_than_one_grid(oracle):
     text.free()
 
 
-def test_kmp_speculative_halves(oracle):
-    """kmp_runs on a large alphabet speculates whole 64-byte halves (sixteen independent four-byte steps, one ballot): the
-    exceptions — an occurrence, P[0..4) alone, a match that continues across a dword — must send the half through the
-    ordinary forms.  Texts with all of them planted, against the oracle, with the speculation on and off (tune(3,4))."""
+def test_kmp_four_bytes_per_step(oracle):
+    """kmp_runs on patterns over at most four symbols takes four text bytes per table step (kmp_runs<.., FOUR>,
+    tables.cpp kmp_four_tables): occurrences that end anywhere in a dword, at every boundary, dense and overlapping ones,
+    text bytes that are none of the pattern's symbols (the dword then takes its byte steps), symbols that are not 0..3
+    (ACGT), windows beyond 62 bytes (the prefix's automaton + verification) — against the oracle, with the table and
+    without it (tune(3,5): round 2's kernel on the same tables)."""
     from smart_amd import engine
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(6)
     n = 3 << 20
-    for m in (9, 16, 33, 62, 63, 254, 300):
-        T = oracle.gen_text(4242 + m, 128, 0, n)
-        P = T[100_000:100_000 + m].copy()
-        assert smart_amd.kernel_for("kmp", P) == "kmp_runs"
-        for k in rng.integers(0, n - m, 200):          # whole occurrences, anywhere (any half / line / run boundary)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for sigma, letters, m in ((2, None, 9), (2, None, 16), (4, None, 33), (4, acgt, 62), (4, acgt, 63), (2, None, 254), (3, None, 300), (4, acgt, 2), (2, None, 5)):
+        T = oracle.gen_text(777 + m, sigma, 0, n)
+        if letters is not None:
+            T = letters[T]
+        P = T[200_000:200_000 + m].copy()
+        for k in rng.integers(0, n - m, 300):            # whole occurrences anywhere, some overlapping
             T[k:k + m] = P
-        for k in rng.integers(0, n - 8, 2000):         # P[0..4) alone, and prefixes of 5..8 bytes that then break off
-            j = int(rng.integers(4, 9))
-            T[k:k + j] = P[:j]
-        T[n - m:] = P                                    # an occurrence at the very end
+        T[rng.integers(0, n, 5000)] = 200                # bytes that are none of the pattern's symbols
+        T[n - m:] = P
         text = Text.upload(T)
         want = oracle.search("kmp", P, T)
         assert want >= 100
-        got_on = smart_amd.search("kmp", P, text)[0]
-        engine.tune(3, 4)
+        engine.tune(0, 1)  # KMP on its own kernel at any length
         try:
-            got_off = smart_amd.search("kmp", P, text)[0]
+            assert smart_amd.kernel_for("kmp", P) == "kmp_runs"
+            got_four = smart_amd.search("kmp", P, text)[0]
+            engine.tune(3, 5)
+            got_plain = smart_amd.search("kmp", P, text)[0]
+            sub = smart_amd.search("kmp", P, text, off=123_457, n=1_500_001)[0]
         finally:
             engine.tune(3, 0)
-        assert got_on == want and got_off == want, (m, got_on, got_off, want)
-        sub = smart_amd.search("kmp", P, text, off=123_457, n=1_500_001)[0]
-        assert sub == oracle.search("kmp", P, T[123_457:123_457 + 1_500_001]), m
+            engine.tune(0, 0)
+        assert got_four == want and got_plain == want, (sigma, m, got_four, got_plain, want)
+        assert sub == oracle.search("kmp", P, T[123_457:123_457 + 1_500_001]), (sigma, m)
         text.free()
