@@ -94,6 +94,11 @@ int smartgpu_text_device(const smartgpu_text *t);
 /* Copies text[off..off+len) back to the host (tests, pattern extraction à la
  * setOfRandomPatterns, src/smart.c:148-158). */
 int smartgpu_text_read(const smartgpu_text *t, uint64_t off, uint64_t len, void *host);
+/* Which byte values the text holds: bit c of bits[8] (bit c%32 of word c/32) is set iff some text byte equals c.
+ * Taken once, on the device, when the text is created (the reference's getText, src/smart.c:95-138, reads the corpus
+ * once per run as well; a text is never written afterwards).  The runs kernels use it: on a text of at most four
+ * distinct values they take four bytes per table step. */
+int smartgpu_text_alphabet(const smartgpu_text *t, uint32_t bits[8]);
 
 /* ---- searching -------------------------------------------------------- */
 /* Counts the occurrences of P[0..m) whose window lies inside text[off..off+n),
@@ -229,10 +234,12 @@ int smartgpu_probe_read_ms(const smartgpu_text *t, int reps, double *ms_per_pass
  *   2  bm_scan / bndm_scan workgroups: 1 four waves / 2 two waves (0 = default: bm_scan two where the pattern's symbols
  *      repeat, bndm_scan always four)
  *   3  KMP: 0 kmp_runs (transition table) / 1 kmp_scan (LDS tiles, m <= 40) / 2 kmp_links_runs
- *      (failure links followed per byte) / 5 kmp_runs without its four-bytes-per-step table (round 3)
+ *      (failure links followed per byte) / 5 kmp_runs a byte per table step even on a text of at most four
+ *      byte values (round 3: there it takes four)
  *   5  run length in bytes of the runs kernels (so_runs, kmp_runs); 0 = default
  *   6  SO: 0 so_runs (bank-private table, line fetch) / 1 so_scan (LDS tiles) / 2 so_runs64
- *      (shared table, 64-byte steps); SA: 3 = its own AND form (default: the complemented, Shift-Or form)
+ *      (shared table, 64-byte steps); SA: 3 = its own AND form (default: the complemented, Shift-Or form);
+ *      5 so_runs a byte per table lookup even on a text of at most four byte values (round 3: there it takes four)
  *   7  packed matcher load policy: 0 A non-temporal + B cached / 1 both cached / 3 one load + shuffle */
 int smartgpu_tune(int key, int value);
 
@@ -248,8 +255,9 @@ int smartgpu_tune(int key, int value);
  *          6 the same over the pattern's own alphabet: k1, colmap[256], table[(m+1)*k1]
  *          7 Shift-And masks S[256] (sa.c:27-34), 8 Quick Search shifts qsBc[256] (qs.c:27-31),
  *          9 kmp_runs' tables as the kernel holds them in LDS (bytes; the last 272: Q and thr),
- *          10 kmp_runs' four-bytes-per-step table for patterns over at most four symbols:
- *            (w+1)*256 entries (w = min(m, 62)), then shift and symtab; 0 entries when the pattern does not qualify,
+ *          10 the two-bit codes of the byte values of P taken as a SET (what the runs kernels use on a text of at most
+ *            four byte values): shift, symtab — code (c >> shift) & 3, byte `code` of symtab = the member with that code
+ *            (a non-member with that code if none); 0 entries when there are more than four or no shift separates them,
  *          13/15/18 HASH3/5/8 shifts[256] followed by the shift after a candidate (hash3.c:36-56)   */
 int smartgpu_build_table(int which, const uint8_t *P, uint32_t m, int32_t *out, uint32_t cap);
 

@@ -107,6 +107,10 @@ struct smartgpu_text {
     uint64_t n = 0;
     uint8_t* base = nullptr;  // allocation start; text byte 0 at base + kFrontPad
     const uint8_t* data() const { return base + sg::kFrontPad; }
+    // what the text consists of, taken once when it is created (text_alphabet below): the byte values that occur, and
+    // — for at most four of them — their two-bit codes (ScanArgs.four_shift, four_symtab; 7: none)
+    uint32_t alphabet[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t four_shift = 7, four_symtab = 0;
 };
 
 struct smartgpu_plan {
@@ -163,6 +167,22 @@ smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
     }
     *ctx_out = d;
     return t;
+}
+
+// One pass over a text that has just been written (upload, tile fill, generator): which byte values it holds.  A text
+// is never written again (ownership), so the answer holds for every later search, of any part of it.
+bool text_alphabet(smartgpu_text* t, DeviceCtx* d)
+{
+    uint32_t* dev = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&dev), 32) != hipSuccess) { set_error("hipMalloc of the alphabet bits failed"); return false; }
+    hipError_t e = hipMemsetAsync(dev, 0, 32, d->stream);
+    if (e == hipSuccess && t->n) e = sg::launch_text_alphabet(t->data(), t->n, dev, d->num_cus, d->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->alphabet, dev, 32, hipMemcpyDeviceToHost, d->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+    hipFree(dev);
+    if (e != hipSuccess) { set_error("text_alphabet failed: %s", hipGetErrorString(e)); return false; }
+    if (!sg::four_symbol_codes(t->alphabet, &t->four_shift, &t->four_symtab)) t->four_shift = 7;
+    return true;
 }
 
 // Build the device blob (pattern + tables) for (algo, P, m) in `blob` (cleared first; a caller that builds many
@@ -277,17 +297,20 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
             // kmp_runs: the automaton over w = kmp_window(m) bytes (the pattern, or its 62-byte prefix beyond 254) with an ABSORBING accept row Z (every transition into
             // the accept state w leads to Z, Z leads to Z; row id(w) holds the real delta(w, .)), and the table of the
             // four-bytes-at-a-time forms (tables.cpp)
-            // ... over at most four symbols (DNA-like alphabets): a second table that takes FOUR text bytes per step
-            // (tables.cpp kmp_four_tables) — the window is then the pattern or its 62-byte prefix (the table lives in the gaps
-            // of the byte table, whose ids are 4s up to 62 states); its length travels as the plan's prefer_packed field
-            std::vector<uint8_t> four;
+            // A pattern over at most four symbols (DNA-like alphabets): on a text that itself holds at most four byte values
+            // kmp_runs takes FOUR text bytes per table step (kmp_runs<., FOUR>; the table lives in the gaps of the byte table,
+            // whose ids are 4s up to 62 states, and is derived from it on the device) — the window is then the pattern or
+            // its 62-byte prefix; its length travels as the plan's prefer_packed field
             const uint32_t w4 = std::min<uint32_t>(m, sg::kKmpPrefix);
-            const bool has4 = m >= 2 && sg::kmp_four_tables(P, w4, four);
-            sg::kmp_runs_tables(P, has4 ? w4 : sg::kmp_window(m), blob);
-            if (has4) {
-                append(four.data(), four.size());
-                *prefer_packed = w4;
+            uint32_t distinct4 = 0;
+            {
+                bool have[256] = {false};
+                for (uint32_t i = 0; i < w4; ++i)
+                    if (!have[P[i]]) { have[P[i]] = true; ++distinct4; }
             }
+            const bool has4 = m >= 2 && distinct4 <= 4;
+            sg::kmp_runs_tables(P, has4 ? w4 : sg::kmp_window(m), blob);
+            if (has4) *prefer_packed = w4;
 #ifdef SMARTGPU_AB
             {   // kmp_runs1 (A/B build): the automaton of P[0..w), w = min(m, 255); state s is row id(s) = rotl8(s, 2),
                 // the accept state row 255 — or row 4w while the ids 4s do not wrap (w < 64) —, the largest id (its
@@ -500,6 +523,8 @@ sg::ScanArgs make_args(const smartgpu_plan* p, const smartgpu_text* text, uint64
     a.so_off = p->so_off;
     a.blob = p->blob;
     a.count = p->slot_ptr(slot);
+    a.four_shift = text->four_shift;
+    a.four_symtab = text->four_symtab;
     return a;
 }
 
@@ -568,6 +593,7 @@ smartgpu_text* smartgpu_text_upload(const void* host, uint64_t n, int device)
         done += chunk;
     }
     hipStreamSynchronize(d->stream);
+    if (!text_alphabet(t, d)) { smartgpu_text_free(t); return nullptr; }
     return t;
 }
 
@@ -588,6 +614,7 @@ smartgpu_text* smartgpu_text_upload_tiled(const void* unit, uint64_t unit_len, u
         smartgpu_text_free(t);
         return nullptr;
     }
+    if (!text_alphabet(t, d)) { smartgpu_text_free(t); return nullptr; }
     return t;
 }
 
@@ -604,6 +631,7 @@ smartgpu_text* smartgpu_text_generate(uint64_t seed, int sigma, uint64_t off, ui
         smartgpu_text_free(t);
         return nullptr;
     }
+    if (!text_alphabet(t, d)) { smartgpu_text_free(t); return nullptr; }
     return t;
 }
 
@@ -619,6 +647,13 @@ void smartgpu_text_free(smartgpu_text* t)
 
 uint64_t smartgpu_text_length(const smartgpu_text* t) { return t ? t->n : 0; }
 int smartgpu_text_device(const smartgpu_text* t) { return t ? t->device : -1; }
+
+int smartgpu_text_alphabet(const smartgpu_text* t, uint32_t bits[8])
+{
+    if (!t || !bits) { set_error("bad alphabet arguments"); return SMARTGPU_ERR_ARG; }
+    std::memcpy(bits, t->alphabet, 32);
+    return SMARTGPU_OK;
+}
 
 int smartgpu_text_read(const smartgpu_text* t, uint64_t off, uint64_t len, void* host)
 {
@@ -944,6 +979,8 @@ sg::ScanArgs batch_args(const BatchPlan& bp, const DeviceCtx* d, uint32_t m, con
     a.so_off = bp.so_off;
     a.blob = d->arena + bp.off;
     a.count = slot;
+    a.four_shift = text->four_shift;
+    a.four_symtab = text->four_symtab;
     return a;
 }
 
@@ -1394,15 +1431,12 @@ int smartgpu_build_table(int which, const uint8_t* P, uint32_t m, int32_t* out, 
             v.assign(t.begin(), t.end());
             break;
         }
-        case 10: {  // kmp_runs' four-bytes-per-step table: (w+1)*256 entries, then shift, symtab (w = min(m, 62)); no entries: not applicable
-            std::vector<uint8_t> t;
-            const uint32_t w = std::min<uint32_t>(m, sg::kKmpPrefix);
-            if (sg::kmp_four_tables(P, w, t)) {
-                v.assign(t.begin(), t.begin() + (w + 1) * 256);
-                uint32_t par[2];
-                std::memcpy(par, t.data() + (w + 1) * 256, 8);
-                v.push_back(static_cast<int32_t>(par[0]));
-                v.push_back(static_cast<int32_t>(par[1]));
+        case 10: {  // the two-bit codes of the byte values in P[0..m) taken as a SET (a text's alphabet): shift, symtab; no entries: none
+            uint32_t set[8] = {0, 0, 0, 0, 0, 0, 0, 0}, shift = 7, symtab = 0;
+            for (uint32_t i = 0; i < m; ++i) set[P[i] >> 5] |= 1u << (P[i] & 31);
+            if (sg::four_symbol_codes(set, &shift, &symtab)) {
+                v.push_back(static_cast<int32_t>(shift));
+                v.push_back(static_cast<int32_t>(symtab));
             }
             break;
         }

@@ -1432,7 +1432,15 @@ static __device__ __attribute__((noinline)) uint64_t so_long_hits(const uint8_t*
     return ((uint64_t)n << 32) | parked_off;
 }
 
-template <bool LONG>  // LONG: m > 29, hits of the 29-byte prefix are verified
+// FOUR — a text of at most four distinct byte values (ScanArgs.four_shift, four_symtab: what the text consists of is
+// known since it was created): the per-lane table holds, instead of the 256 masks, the 256 values
+//     S4[c0 | c1 << 2 | c2 << 4 | c3 << 6] = (S'[sym(c0)] << 3) | (S'[sym(c1)] << 2) | (S'[sym(c2)] << 1) | S'[sym(c3)]
+// of four consecutive symbols given by their two-bit codes c = (byte >> shift) & 3 — the operand of the step above,
+// ready-made.  Per four text bytes: v_lshrrev + v_and (codes), v_dot4_u32_u8 (index), v_lshl_or (address), ONE gather,
+// v_lshl_or (D), v_alignbit (hits) — 1.5 VALU ops and a quarter LDS gather per byte against 2.25 and one.  The few
+// bytes of a run's first and last halves go a byte at a time through one shared copy of the 256 masks (at most four
+// addresses per wave: no conflicts to speak of).
+template <bool LONG, bool FOUR>  // LONG: m > 29, hits of the 29-byte prefix are verified
 __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns, const BatchItem* __restrict__ batch)
 {
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
@@ -1443,10 +1451,21 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
     const RunIo io = swap_io(smem + 65536 + wave * kLineSlab, lane, run_len);
     const uint32_t sh = 29u - w;
     const uint32_t sentinel = (0xFFFFFFFFu << sh) & 0x1FFFFFFFu;  // mask of a byte outside the lane's range
-    {   // expand the 256 masks to one copy per lane through a 1 KB staging area (wave 0's slab)
+    constexpr uint32_t kS1 = 65536 + kRunWaves * kLineSlab;  // FOUR: LDS offset of ONE copy of the masks
+    {   // expand the 256 masks (FOUR: the 256 four-symbol values) to one copy per lane through a 1 KB staging area (wave 0's slab)
         uint32_t* stage = reinterpret_cast<uint32_t*>(smem + 65536);
-        if (threadIdx.x < 256)
-            stage[threadIdx.x] = (reinterpret_cast<const uint32_t*>(a.blob + a.so_off)[threadIdx.x] << sh) & 0x1FFFFFFFu;
+        const uint32_t* Sg = reinterpret_cast<const uint32_t*>(a.blob + a.so_off);
+        auto mask = [&](uint32_t c) { return (Sg[c] << sh) & 0x1FFFFFFFu; };
+        if (threadIdx.x < 256) {
+            if (FOUR) {
+                auto of_code = [&](uint32_t code) { return mask((a.four_symtab >> (8u * (code & 3u))) & 0xFFu); };
+                const uint32_t t = threadIdx.x;
+                stage[t] = (of_code(t) << 3) | (of_code(t >> 2) << 2) | (of_code(t >> 4) << 1) | of_code(t >> 6);
+                reinterpret_cast<uint32_t*>(smem + kS1)[t] = mask(t);
+            } else {
+                stage[threadIdx.x] = mask(threadIdx.x);
+            }
+        }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < 256 * 64; i += kRunWaves * 64) S[i] = stage[i >> 6];
     }
@@ -1500,6 +1519,23 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
                 uint4 v[4];
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) v[c4] = run_piece(io, c4);
+                uint32_t H[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+                if constexpr (FOUR) {
+                    uint32_t t4[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint4& vv = v[i >> 2];
+                        const uint32_t d = (i & 3) == 0 ? vv.x : (i & 3) == 1 ? vv.y : (i & 3) == 2 ? vv.z : vv.w;
+                        const uint32_t c = (d >> a.four_shift) & 0x03030303u;
+                        const uint32_t idx = __builtin_amdgcn_udot4(c, 0x40100401u, 0u, false);  // c0 | c1 << 2 | c2 << 4 | c3 << 6
+                        t4[i] = *(const lds_u32_t*)(size_t)((idx << 8) | lane4);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        D = (D << 4) | t4[i];                                     // four steps of so.c:55
+                        H[i >> 3] = __builtin_amdgcn_alignbit(H[i >> 3], D, 28);  // so.c:56 for the four bytes: bits 28..31
+                    }
+                } else {
                 uint32_t s[2][16];
                 auto gather16 = [&](const uint4& vv, uint32_t* out) {
                     const uint32_t d[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -1508,7 +1544,6 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
                         out[q] = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
                 };
                 gather16(v[0], s[0]);
-                uint32_t H[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
                     if (c4 < 3) gather16(v[c4 + 1], s[(c4 + 1) & 1]);
@@ -1525,6 +1560,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
                         H[c4 >> 1] = __builtin_amdgcn_alignbit(H[c4 >> 1], D, 28);  // so.c:56 for the four bytes: bits 28..31
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                }
                 }
                 if (!LONG) {
                     hits += __popc(~H[0]) + __popc(~H[1]);
@@ -1547,7 +1583,9 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const uint32_t j = base + q;
-                        uint32_t sv = *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
+                        // (an LDS address, not S1[.]: the select below must stay a select of VALUES)
+                        uint32_t sv = FOUR ? *(const lds_u32_t*)(size_t)(kS1 + __builtin_amdgcn_perm(0u, d[q >> 2], 0x0c0c0c00u + (q & 3)) * 4u)
+                                           : *(const lds_u32_t*)(size_t)__builtin_amdgcn_perm(d[q >> 2], lane4, 0x0c0c0400u + ((q & 3) << 8));
                         sv = (j >= j0 && j < jend) ? sv : sentinel;
                         D = (D << 1) | sv;                                // so.c:55
                         H = __builtin_amdgcn_alignbit(H, D << 3, 31);    // so.c:56: bit 28 = bit w-1 of the state
@@ -1665,33 +1703,20 @@ __device__ __forceinline__ void kmp_chunk_skip4(const uint4& v, uint32_t& st, bo
     }
 }
 
-// Sixteen transitions as FOUR table steps of four bytes each (patterns over at most four symbols, tables.cpp
-// kmp_four_tables): the codes (c >> shift) & 3 of a dword's bytes make the index, one v_perm_b32 rebuilds the dword
-// from the symbols of those codes — equal <=> every byte IS one of the pattern's symbols —, and the step is one lookup
-// in row id + 2 (the gaps of the byte table).  Index and check do not depend on the state: only v_or, v_lshl_or, v_xor
-// and the LDS read are on the chain, once per four bytes.  A chunk in which any lane holds any other byte takes the
-// sixteen byte steps.
-__device__ __forceinline__ void kmp_chunk_four(const uint4& v, uint32_t& st, uint32_t shift, uint32_t symtab)
+// Sixteen transitions as FOUR table steps of four bytes each — a text of at most four distinct byte values
+// (ScanArgs.four_shift; the kernel derives the table from the byte table when it starts, see there): the codes
+// (c >> shift) & 3 of a dword's bytes make the index (v_lshrrev, v_and, v_dot4_u32_u8 — none of them on the chain), the
+// step is one lookup in the row r = id + 2 of the state (the gaps of the byte table), whose entries are such rows again:
+// v_lshl_or, v_xor and the LDS read per four bytes.  r: the state as that row, in and out.
+__device__ __forceinline__ void kmp_chunk_four(const uint4& v, uint32_t& r, uint32_t shift)
 {
     const uint32_t d[4] = {v.x, v.y, v.z, v.w};
     uint32_t idx[4];
-    bool valid = true;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t c = (d[k] >> shift) & 0x03030303u;
-        valid = valid && __builtin_amdgcn_perm(symtab, symtab, c) == d[k];
-        const uint32_t t = c | (c >> 6);
-        idx[k] = (t | (t >> 12)) & 0xFFu;  // the first byte's code in bits 0-1, ... the fourth's in bits 6-7
-    }
-    if (__ballot(!valid) == 0) {
+    for (int k = 0; k < 4; ++k)  // the first byte's code in bits 0-1, ... the fourth's in bits 6-7
+        idx[k] = __builtin_amdgcn_udot4((d[k] >> shift) & 0x03030303u, 0x40100401u, 0u, false);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t r = st | 2u;  // ids are 4s here: row 4s + 2
-            st = *(const lds_u8_t*)(size_t)(((r << 8) | idx[k]) ^ r);
-        }
-    } else {
-        kmp_chunk_fast(v, st);
-    }
+    for (int k = 0; k < 4; ++k) r = *(const lds_u8_t*)(size_t)(((r << 8) | idx[k]) ^ r);
 }
 
 // sixteen transitions, counting (MASK: collecting) the entries into Z; CHECK: only bytes j0 <= j < jend
@@ -1726,8 +1751,12 @@ __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base,
 //             on its own made it slower: 0.218-0.232).
 // FOUR — a separate INSTANTIATION, so that what it needs costs round 2's kernel nothing (as a run-time switch, together
 // with a speculation for large alphabets that was dropped, it cost the English and rand32 cells 4-11 % against round 2's
-// build: 124 VGPRs, a larger loop): the plan carries the four-bytes-per-step table (patterns over at most four symbols,
-// api.cpp build_blob; the window is then at most 62 bytes)
+// build: 124 VGPRs, a larger loop): the TEXT holds at most four distinct byte values (ScanArgs.four_shift, four_symtab)
+// and the plan's window is at most 62 bytes (api.cpp build_blob: patterns over at most four symbols).  Row 4s + 2 of the
+// table — the gaps of the byte table — then holds, for every index of four two-bit codes, the row the automaton is in
+// four bytes on from state s: (id | 2), with the absorbing Z | 2 = 4w + 3 if an occurrence ended on the way.  The
+// workgroup computes these rows itself before it starts, four lookups in the byte table per entry (0.5 us), so the
+// codes are the text's own and the plan carries nothing for them.
 template <bool PREFIX, bool FOUR>  // PREFIX: the automaton of the 62-byte prefix (m > 254; FOUR: m > 62); hits are verified
 __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
                                                            uint32_t dfa_off, const BatchItem* __restrict__ batch)
@@ -1752,9 +1781,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     const uint32_t qbase = table_bytes;  // Q[s] = P[s..s+4) for the states kmp_chunk_skip4 covers (256 bytes)
     const uint32_t stored = (w < 63 ? w + 1 : 256u) * 256u;  // the blob's rows (tables.cpp kmp_runs_tables)
     const uint32_t thr = *reinterpret_cast<const uint32_t*>(a.blob + dfa_off + stored + 256);
-    const uint8_t* const blob4 = a.blob + dfa_off + stored + kKmpQBytes;  // the rows of the four-byte table, then shift and symtab
-    const uint32_t shift4 = four ? *reinterpret_cast<const uint32_t*>(blob4 + (w + 1) * 256u) : 0u;
-    const uint32_t symtab4 = four ? *reinterpret_cast<const uint32_t*>(blob4 + (w + 1) * 256u + 4) : 0u;
+    const uint32_t shift4 = a.four_shift;
     uint8_t* const slabs = smem + table_bytes + kKmpQBytes;
     const RunIo io = swap_io(slabs + wave * kLineSlab, lane, run_len);
     {
@@ -1767,10 +1794,9 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
             const uint32_t z4 = Z * 0x01010101u;
             if (threadIdx.x < 16) t[Z * 16 + threadIdx.x] = make_uint4(z4, z4, z4, z4);
             else if (threadIdx.x < 32) t[table_bytes / 16 + threadIdx.x - 16] = g[stored / 16 + threadIdx.x - 16];
-            if (four) {  // row s of the four-byte table goes to row 4s + 2
-                const uint4* g4 = reinterpret_cast<const uint4*>(blob4);
-                for (uint32_t i = threadIdx.x; i < (w + 1) * 16; i += kRunWaves * 64) t[((i >> 4) * 4 + 2) * 16 + (i & 15u)] = g4[i];
-                if (threadIdx.x >= 32 && threadIdx.x < 48) t[(Z + 2) * 16 + threadIdx.x - 32] = make_uint4(z4, z4, z4, z4);
+            if (four && threadIdx.x >= 32 && threadIdx.x < 48) {  // row Z | 2: a lane that fell into Z stays there
+                const uint32_t zz = (Z | 2u) * 0x01010101u;
+                t[(Z + 2) * 16 + threadIdx.x - 32] = make_uint4(zz, zz, zz, zz);
             }
         } else {
             for (uint32_t i = threadIdx.x; i < (table_bytes + 256) / 16; i += kRunWaves * 64) t[i] = g[i];
@@ -1782,7 +1808,20 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
         return;
     }
-    __syncthreads();  // the only workgroup barrier: table visible
+    __syncthreads();  // table visible
+    if (four) {  // the rows 4s + 2: four steps of the byte table for every index of four codes
+        for (uint32_t i = threadIdx.x; i < (w + 1) * 256u; i += kRunWaves * 64) {
+            const uint32_t s = i >> 8, idx = i & 255u, r = 4u * s + 2u;
+            uint32_t st = 4u * s;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = (a.four_symtab >> (8u * ((idx >> (2 * j)) & 3u))) & 0xFFu;
+                st = *(const lds_u8_t*)(size_t)(((st << 8) | c) ^ st);  // kmp_delta
+            }
+            smem[(r << 8) | ((idx ^ r) & 255u)] = (uint8_t)(st | 2u);  // Z | 2 if an occurrence ended on the way
+        }
+        __syncthreads();
+    }
 
     uint32_t hits = 0;
     const uint64_t run_first = a.s_begin / run_len;  // runs are cut on absolute offsets
@@ -1862,11 +1901,13 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
                         }
                         if (nfast < 6) mode = thr >= 16u ? 2u : 0u;
                     } else if (FOUR && mode == 5) {
+                        uint32_t r = st | 2u;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            at[q] = st;
-                            kmp_chunk_four(run_piece(io, q), st, shift4, symtab4);
+                            at[q] = r & ~2u;
+                            kmp_chunk_four(run_piece(io, q), r, shift4);
                         }
+                        st = r & ~2u;
                     } else if (mode == 2) {
                         bool low = kmp_all_low(st, thr);
                         uint32_t nfast = 0;
@@ -2233,6 +2274,37 @@ __global__ __launch_bounds__(256) void tile_fill(uint8_t* dst, const uint8_t* un
         dst[i] = unit[(phase + i) % unit_len];
 }
 
+// Which byte values occur in the text (taken once, when a text is created — api.cpp text_alphabet): every workgroup
+// marks them in LDS and ORs its 256 bits into out[8].
+__global__ __launch_bounds__(256) void text_alphabet(const uint8_t* text, uint64_t n, uint32_t* out)
+{
+    __shared__ uint32_t seen[256];
+    seen[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t n16 = n / 16, stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) {
+        const uint4 v = ld_stream16(text + 16 * i);
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) seen[(d[q >> 2] >> (8 * (q & 3))) & 0xFFu] = 1;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 15u)) seen[text[16 * n16 + threadIdx.x]] = 1;
+    __syncthreads();
+    const uint64_t bits = __ballot(seen[threadIdx.x] != 0);  // wave w of the workgroup: byte values 64w .. 64w+63
+    if ((threadIdx.x & 63u) == 0) {
+        if ((uint32_t)bits) atomicOr(out + 2 * (threadIdx.x >> 6), (uint32_t)bits);
+        if ((uint32_t)(bits >> 32)) atomicOr(out + 2 * (threadIdx.x >> 6) + 1, (uint32_t)(bits >> 32));
+    }
+}
+
+hipError_t launch_text_alphabet(const uint8_t* text, uint64_t n, uint32_t* out, int num_cus, hipStream_t stream)
+{
+    const uint64_t want = (n / 16 + 255) / 256;
+    const uint32_t grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)num_cus * 8));
+    hipLaunchKernelGGL(text_alphabet, dim3(grid), dim3(256), 0, stream, text, n, out);
+    return hipGetLastError();
+}
+
 // Streaming-read probe: the practical HBM read ceiling of this device for the
 // access pattern the scan kernels use (coalesced 16 B/lane, 8 loads in flight per
 // lane, every byte read once).  XOR-folds the text so the loads cannot be elided.
@@ -2323,7 +2395,8 @@ bool tune_supported(int key, int value)
     switch (key) {
         case 0: return value == 0 || value == 1 || value == 3;  // 2: Horspool on the bank-private tiles
         case 3: return value == 0 || value == 5;                 // superseded KMP kernels (5: kmp_runs without its four-byte table)
-        case 6: case 7: return value == 0;                       // superseded SO kernels, packed load policies
+        case 6: return value == 0 || value == 5;                 // superseded SO kernels (5: so_runs without the four-symbol table)
+        case 7: return value == 0;                               // packed load policies
         default: return true;
     }
 #endif
@@ -2476,7 +2549,8 @@ static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus,
     const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin, 128);
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
-    const size_t lds = 65536 + kRunWaves * (size_t)kLineSlab;
+    const bool four = a.four_shift < 7 && g_tune[6] != 5;  // the text consists of at most four symbols
+    const size_t lds = 65536 + kRunWaves * (size_t)kLineSlab + (four ? 1024 : 0);
     const uint64_t grid = runs_grid(tr.count, num_cus);
     trace_runs("so_runs", a, L, tr, grid);
 #ifdef SMARTGPU_AB
@@ -2487,10 +2561,10 @@ static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus,
                            (uint32_t)L, (uint64_t)tr.count, g_batch.items);                              \
     } while (0)
 #endif
-#define SG_SO_RUNS(L_)                                                                                   \
+#define SG_SO_RUNS(L_, F_)                                                                               \
     do {                                                                                                 \
-        allow_lds(reinterpret_cast<const void*>(so_runs<L_>), lds);                                      \
-        hipLaunchKernelGGL((so_runs<L_>), dim3((uint32_t)grid, g_batch.count), dim3(64 * kRunWaves), lds, stream, a, \
+        allow_lds(reinterpret_cast<const void*>(so_runs<L_, F_>), lds);                                  \
+        hipLaunchKernelGGL((so_runs<L_, F_>), dim3((uint32_t)grid, g_batch.count), dim3(64 * kRunWaves), lds, stream, a, \
                            (uint32_t)L, (uint64_t)tr.count, g_batch.items);                              \
     } while (0)
 #ifdef SMARTGPU_AB
@@ -2499,7 +2573,10 @@ static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus,
     else
 #undef SG_SO_RUNS1
 #endif
-    { if (m > kSoWindow) SG_SO_RUNS(true); else SG_SO_RUNS(false); }
+    {
+        if (four) { if (m > kSoWindow) SG_SO_RUNS(true, true); else SG_SO_RUNS(false, true); }
+        else { if (m > kSoWindow) SG_SO_RUNS(true, false); else SG_SO_RUNS(false, false); }
+    }
     (void)shift_and;
 #undef SG_SO_RUNS
     return hipGetLastError();
@@ -2509,13 +2586,15 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
 {
     const uint32_t m = a.m;
     const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));  // the transition table of kmp_runs (api.cpp build_blob)
-    const bool four = a.prefer_packed != 0 && g_tune[3] != 5;   // the plan carries the four-bytes-per-step table (tune(3,5): unused, A/B)
+    // four text bytes per table step: the text holds at most four byte values and the plan's window is short enough for
+    // the table (a pattern over at most four symbols — any other cannot occur in such a text); tune(3,5): never (A/B)
+    const bool four = a.prefer_packed != 0 && a.four_shift < 7 && g_tune[3] != 5;
     uint32_t w = a.prefer_packed ? a.prefer_packed : kmp_window(m);  // bytes the automaton recognises (with that table: api.cpp); a run re-scans w-1
     const uint32_t rows = (w < 63 ? 4 * w + 2 : 256) + (four ? 2 : 0);  // up to the absorbing row Z (+ rows 4w+2, 4w+3 of the four-byte table)
 #ifdef SMARTGPU_AB
     const bool links = g_tune[3] == 2;  // failure links
     const bool v1 = g_tune[3] == 3;     // the previous kernel (running maximum, half-line loader): its table follows
-    const uint32_t dfa1_off = dfa_off + (w < 63 ? w + 1 : 256u) * 256 + kKmpQBytes + (a.prefer_packed ? (w + 1) * 256 + 16 : 0);
+    const uint32_t dfa1_off = dfa_off + (w < 63 ? w + 1 : 256u) * 256 + kKmpQBytes;
     if (links || v1) w = (links || m <= kKmpDfaMaxM) ? m : kKmpDfaMaxM;
     if (links) {
         const uint64_t span = a.s_end - a.s_begin;

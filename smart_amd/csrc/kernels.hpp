@@ -46,6 +46,11 @@ struct ScanArgs {
                                 // for other algorithms when the pattern is best counted by so_runs (else 0)
     const uint8_t* blob;        // device: [pattern kPatternBytes][tables ...]
     unsigned long long* count;  // device result slot (pre-zeroed)
+    // What the TEXT consists of (api.cpp text_alphabet, taken once when the text is created): at most four distinct
+    // byte values whose bits shift, shift+1 tell them apart — four_shift < 7, four_symtab = the byte value of each
+    // two-bit code (unused codes: a byte the text does not hold) — or four_shift = 7.  The runs kernels then take
+    // four text bytes per table step (so_runs<., true>; kmp_runs<., true> when the plan's table speaks the same codes).
+    uint32_t four_shift = 7, four_symtab = 0;
 };
 
 // One pattern of a set that runs as ONE grid (launch_scan_set): what differs from pattern to pattern.  Everything
@@ -98,6 +103,8 @@ hipError_t launch_generate(uint8_t* dst, uint64_t seed, int sigma, uint64_t off,
 hipError_t launch_tile_fill(uint8_t* dst, const uint8_t* unit, uint64_t unit_len, uint64_t phase,
                             uint64_t n, hipStream_t stream);
 
+// out[8] (device, zeroed by the caller): bit c set <=> byte value c occurs in text[0, n)
+hipError_t launch_text_alphabet(const uint8_t* text, uint64_t n, uint32_t* out, int num_cus, hipStream_t stream);
 hipError_t launch_probe_read(const uint8_t* text, uint64_t n, unsigned long long* sink, int num_cus,
                              hipStream_t stream);
 

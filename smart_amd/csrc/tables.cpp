@@ -97,78 +97,33 @@ std::vector<uint8_t> kmp_dfa(const uint8_t* P, uint32_t m)
 
 uint32_t kmp_runs_table_bytes(uint32_t w) { return (w < 63 ? w + 1 : 256u) * 256u; }
 
-// kmp_runs on an alphabet of at most four symbols: FOUR text bytes per table step.  The symbols of P[0..w) are told
-// apart by two bits of their byte value, (c >> shift) & 3 — the smallest shift for which the codes differ; none: no
-// table —, four codes make an 8-bit index (the first byte's code in bits 0-1), and row s of the table holds, for every
-// index, the state the automaton of kmp.c:27-68 is in four bytes on from state s: id 4t, or Z (the absorbing row of
-// kmp_runs_tables) if it passed through the accept state w on the way.  A code no symbol of the pattern has acts as
-// "a byte that is not in the pattern" (state 0); the kernel checks every text dword against symtab — the symbol of each
-// code, for an unused code a byte with a different code, so that it can never compare equal — and falls back to a
-// lookup per byte for a dword that holds anything else.  Rows are stored one after the other, row s swizzled by the
-// id 4s + 2 of the LDS row it is spread to (the gaps of the byte table: ids 4s, so w < 63).  16 bytes of parameters
-// follow: u32 shift, u32 symtab.  Returns false (and appends nothing) when the pattern does not qualify.
-bool kmp_four_tables(const uint8_t* P, uint32_t w, std::vector<uint8_t>& out)
+// The two-bit codes of a text of at most four distinct byte values (so_runs<., FOUR>, kmp_runs<., FOUR>: four text
+// bytes per table step, the codes (c >> shift) & 3 of a dword's bytes make an 8-bit index — the kernels derive their
+// four-byte tables from the byte tables when they start).
+bool four_symbol_codes(const uint32_t set[8], uint32_t* shift, uint32_t* symtab)
 {
-    if (w >= 63 || w < 2) return false;
-    bool have[256] = {false};
-    uint32_t distinct = 0;
     uint8_t syms[4];
-    for (uint32_t i = 0; i < w; ++i)
-        if (!have[P[i]]) {
+    uint32_t distinct = 0;
+    for (uint32_t c = 0; c < 256; ++c)
+        if (set[c >> 5] >> (c & 31) & 1u) {
             if (distinct == 4) return false;
-            have[P[i]] = true;
-            syms[distinct++] = P[i];
+            syms[distinct++] = static_cast<uint8_t>(c);
         }
-    uint32_t shift = 7;
-    for (uint32_t sh = 0; sh < 7 && shift == 7; ++sh) {
-        bool used[4] = {false, false, false, false}, ok = true;
+    for (uint32_t sh = 0; sh < 7; ++sh) {
+        int sym_of[4] = {-1, -1, -1, -1};
+        bool ok = true;
         for (uint32_t i = 0; i < distinct && ok; ++i) {
             const uint32_t c = (syms[i] >> sh) & 3u;
-            ok = !used[c];
-            used[c] = true;
+            ok = sym_of[c] < 0;
+            sym_of[c] = syms[i];
         }
-        if (ok) shift = sh;
+        if (!ok) continue;
+        *shift = sh;
+        *symtab = 0;
+        for (uint32_t c = 0; c < 4; ++c) *symtab |= static_cast<uint32_t>(sym_of[c] >= 0 ? sym_of[c] : static_cast<int>(c << sh)) << (8 * c);
+        return true;
     }
-    if (shift == 7) return false;
-    int sym_of[4] = {-1, -1, -1, -1};
-    for (uint32_t i = 0; i < distinct; ++i) sym_of[(syms[i] >> shift) & 3u] = syms[i];
-    uint32_t symtab = 0;
-    for (uint32_t c = 0; c < 4; ++c) {
-        const uint32_t b = sym_of[c] >= 0 ? static_cast<uint32_t>(sym_of[c]) : (((c + 1) & 3u) << shift);  // a byte whose code is not c
-        symtab |= b << (8 * c);
-    }
-    uint8_t bd[64];  // longest proper border of P[0..s)
-    bd[0] = bd[1] = 0;
-    for (uint32_t s = 2, k = 0; s <= w; ++s) {
-        while (k && P[s - 1] != P[k]) k = bd[k];
-        if (P[s - 1] == P[k]) ++k;
-        bd[s] = static_cast<uint8_t>(k);
-    }
-    auto delta = [&](uint32_t s, int c) -> uint32_t {  // kmp.c:55-60 as a transition
-        if (c < 0) return 0;
-        if (s == w) s = bd[w];
-        while (s > 0 && P[s] != c) s = bd[s];
-        return P[s] == c ? s + 1 : 0;
-    };
-    const uint32_t Z = 4 * w + 1;
-    const size_t base = out.size();
-    out.resize(base + (w + 1) * 256u + 16, 0);
-    uint8_t* const tab = out.data() + base;
-    for (uint32_t s = 0; s <= w; ++s) {
-        const uint32_t r = 4 * s + 2;
-        for (uint32_t idx = 0; idx < 256; ++idx) {
-            uint32_t t = s;
-            bool hit = false;
-            for (uint32_t j = 0; j < 4; ++j) {
-                t = delta(t, sym_of[(idx >> (2 * j)) & 3u]);
-                hit = hit || t == w;
-            }
-            tab[s * 256u + ((idx ^ r) & 255u)] = static_cast<uint8_t>(hit ? Z : 4 * t);
-        }
-    }
-    std::memcpy(tab + (w + 1) * 256u, &shift, 4);
-    std::memcpy(tab + (w + 1) * 256u + 4, &symtab, 4);
-    return true;
+    return false;
 }
 
 void kmp_runs_tables(const uint8_t* P, uint32_t w, std::vector<uint8_t>& out)

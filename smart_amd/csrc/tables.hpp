@@ -40,9 +40,10 @@ std::vector<uint8_t> kmp_dfa_compressed(const uint8_t* P, uint32_t m, uint32_t* 
 // Built row by row from the border's row like kmp_dfa, in place.
 void kmp_runs_tables(const uint8_t* P, uint32_t w, std::vector<uint8_t>& out);
 uint32_t kmp_runs_table_bytes(uint32_t w);
-// kmp_runs' four-bytes-per-step table for patterns over at most four symbols (w < 63): (w+1)*256 bytes + 16 bytes of
-// parameters (u32 shift, u32 symtab) appended to `out`; false if the pattern does not qualify (tables.cpp)
-bool kmp_four_tables(const uint8_t* P, uint32_t w, std::vector<uint8_t>& out);
+// Two-bit codes for a set of at most four byte values (bit c of the 256-bit set <=> value c is a member): the lowest
+// shift < 7 such that (c >> shift) & 3 tells the members apart, and symtab = the member of each code in byte `code`
+// (a code without a member: a byte value with that code — not a member).  false: more than four members, or no such shift.
+bool four_symbol_codes(const uint32_t set[8], uint32_t* shift, uint32_t* symtab);
 
 // Shift-Or: S[c] has bit i clear iff P[i]==c, over the first w=min(m,32) bytes
 // (so.c:27-38,73-74).  The hit test "D < lim" (so.c:56) is "bit w-1 of D is 0".

@@ -72,6 +72,7 @@ def _load(path):
         "smartgpu_text_length": (u64, [vp]),
         "smartgpu_text_device": (i32, [vp]),
         "smartgpu_text_read": (i32, [vp, u64, u64, vp]),
+        "smartgpu_text_alphabet": (i32, [vp, vp]),
         "smartgpu_search64": (i32, [i32, vp, u32, vp, u64, u64, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "smartgpu_search_batch64": (i32, [i32, vp, u32, u32, vp, u64, u64, vp, vp, vp, C.POINTER(C.c_double)]),
         "smartgpu_msearch_batch64": (i32, [i32, vp, u32, u32, vp, i32, vp, vp, C.POINTER(C.c_double)]),
@@ -174,6 +175,13 @@ class Text:
         if lib().smartgpu_text_read(self._h, off, length, out.ctypes.data) != 0:
             raise _err("text_read")
         return out
+
+    def alphabet(self):
+        """The byte values the text holds, ascending (taken on the device when the text was created)."""
+        bits = np.zeros(8, dtype=np.uint32)
+        if lib().smartgpu_text_alphabet(self._h, bits.ctypes.data) != 0:
+            raise _err("text_alphabet")
+        return [c for c in range(256) if (int(bits[c >> 5]) >> (c & 31)) & 1]
 
     def pattern(self, k, m):
         """P = T[k..k+m), as setOfRandomPatterns cuts it (smart.c:148-158)."""
@@ -419,8 +427,8 @@ def kernel_for(algo, P):
 def build_table(which, P):
     P = _u8(P)
     names = {"bad_char": 0, "good_suffix": 1, "kmp_next": 2, "shift_or": 3, "bndm": 4, "kmp_dfa": 5,
-             "kmp_dfa_compressed": 6, "shift_and": 7, "quick_search": 8, "kmp_runs": 9, "kmp_four": 10, "hash3": 13, "hash5": 15, "hash8": 18}
-    out = np.empty(max(257, len(P) + 1, (len(P) + 1) * 256 + 257 if which.startswith("kmp_dfa") else 256 * 256 + 272 if which in ("kmp_runs", "kmp_four") else 0), dtype=np.int32)
+             "kmp_dfa_compressed": 6, "shift_and": 7, "quick_search": 8, "kmp_runs": 9, "four_codes": 10, "hash3": 13, "hash5": 15, "hash8": 18}
+    out = np.empty(max(257, len(P) + 1, (len(P) + 1) * 256 + 257 if which.startswith("kmp_dfa") else 256 * 256 + 272 if which == "kmp_runs" else 0), dtype=np.int32)
     k = lib().smartgpu_build_table(names[which], P.ctypes.data, len(P), out.ctypes.data, len(out))
     if k < 0:
         raise _err("build_table")

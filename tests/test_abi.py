@@ -302,40 +302,22 @@ def test_product_library_carries_no_superseded_kernels():
     assert smart_amd.kernel_for("kmp", b"abcdabcdabcd") == "kmp_runs"
 
 
-def test_kmp_four_byte_table_is_four_steps_of_the_automaton(oracle):
-    """kmp_runs on patterns over at most four symbols: the table that takes FOUR text bytes per step (tables.cpp
-    kmp_four_tables) against four steps of the plain transition table (build_table "kmp_dfa"), for every state and every
-    index; entries that pass through the accept state say Z; a fifth symbol, or symbols whose two-bit codes collide at
-    every shift, disqualify the pattern."""
-    rng = np.random.default_rng(3)
-    pats = [np.frombuffer(b"ACGTACGTTGCAAC", dtype=np.uint8), rng.integers(0, 2, 16, dtype=np.uint8), rng.integers(0, 4, 62, dtype=np.uint8),
-            rng.integers(0, 4, 200, dtype=np.uint8), np.frombuffer(b"abababababab", dtype=np.uint8), np.frombuffer(b"aaaaaaaaa", dtype=np.uint8),
-            np.array([7, 7, 200, 7, 200, 200, 7, 33, 33], dtype=np.uint8)]
-    for P in pats:
-        got = smart_amd.build_table("kmp_four", P)
-        w = min(len(P), 62)
-        assert len(got) == (w + 1) * 256 + 2, len(P)
-        tab = got[:(w + 1) * 256].astype(np.uint8).reshape(w + 1, 256)
-        shift, symtab = int(got[-2]), int(got[-1]) & 0xFFFFFFFF
-        syms = sorted(set(P[:w].tolist()))
-        codes = {c: (c >> shift) & 3 for c in syms}
-        assert len(set(codes.values())) == len(syms)
-        sym_of = {v: k for k, v in codes.items()}
-        for c in range(4):  # symtab: the symbol of each code; an unused code's entry has another code
+def test_four_symbol_codes():
+    """The two-bit codes the runs kernels use on a text of at most four distinct byte values (tables.cpp
+    four_symbol_codes; build_table "four_codes" takes the set of P's bytes): the lowest shift whose two bits tell the
+    members apart, symtab = the member of each code — for a code without a member a byte with that code that is NOT a
+    member; a fifth value, or values whose codes collide at every shift: none."""
+    for values in ([0, 1, 2, 3], [0, 1], [1], [65, 67, 71, 84], [7, 200], [10, 11, 13], [0x10, 0x20, 0x30], [255, 254, 253, 252], [0, 4, 8, 12], [0, 64, 128, 192]):
+        got = smart_amd.build_table("four_codes", np.array(values * 3, dtype=np.uint8))
+        assert len(got) == 2, values
+        shift, symtab = int(got[0]), int(got[1]) & 0xFFFFFFFF
+        codes = {v: (v >> shift) & 3 for v in values}
+        assert 0 <= shift < 7 and len(set(codes.values())) == len(values), (values, shift)
+        assert all(len({(v >> sh) & 3 for v in values}) < len(values) for sh in range(shift)), (values, shift)  # the lowest
+        for c in range(4):
             b = (symtab >> (8 * c)) & 0xFF
-            assert b == sym_of[c] if c in sym_of else ((b >> shift) & 3) != c
-        dfa = smart_amd.build_table("kmp_dfa", P[:w]).reshape(w + 1, 256)
-        Z = 4 * w + 1
-        for s in range(w + 1):
-            r = 4 * s + 2
-            for idx in range(256):
-                t, hit = s, False
-                for j in range(4):
-                    c = (idx >> (2 * j)) & 3
-                    t = int(dfa[t, sym_of[c]]) if c in sym_of else 0
-                    hit = hit or t == w
-                assert tab[s, (idx ^ r) & 255] == (Z if hit else 4 * t), (len(P), s, idx)
-    five = np.array([1, 2, 3, 4, 5, 1, 2, 3, 4], dtype=np.uint8)
-    assert len(smart_amd.build_table("kmp_four", five)) == 0
-    clash = np.array([0x00, 0x04, 0x10, 0x40, 0x00, 0x04, 0x10, 0x40, 0x04], dtype=np.uint8)  # any two bits of these tell at most three apart
-    assert len(smart_amd.build_table("kmp_four", clash)) == 0
+            assert (b >> shift) & 3 == c
+            assert (b in values) == (c in codes.values()) and (b not in values or codes[b] == c), (values, c, b)
+    assert len(smart_amd.build_table("four_codes", np.array([1, 2, 3, 4, 5], dtype=np.uint8))) == 0
+    assert len(smart_amd.build_table("four_codes", np.array([0x00, 0x04, 0x10, 0x40], dtype=np.uint8))) == 0  # any two bits tell at most three apart
+    assert len(smart_amd.build_table("four_codes", np.array([0, 1, 2, 4], dtype=np.uint8))) == 0

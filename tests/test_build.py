@@ -39,7 +39,7 @@ def test_no_product_kernel_uses_scratch():
     for k, v in scan.items():
         assert v.get("scratch") == 0, (k, v)
     runs = {k: v for k, v in scan.items() if re.search(r"(so_runs|kmp_runs)I", k)}
-    assert len(runs) == 6, sorted(runs)  # so_runs<LONG> x 2, kmp_runs<PREFIX, FOUR> x 4
+    assert len(runs) == 8, sorted(runs)  # so_runs<LONG, FOUR> x 4, kmp_runs<PREFIX, FOUR> x 4
     for k, v in runs.items():
         assert v["vgprs"] <= 128, (k, v)
 

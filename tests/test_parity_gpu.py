@@ -616,25 +616,32 @@ def test_pattern_set_larger_than_one_grid(oracle):
 
 
 def test_kmp_four_bytes_per_step(oracle):
-    """kmp_runs on patterns over at most four symbols takes four text bytes per table step (kmp_runs<.., FOUR>,
-    tables.cpp kmp_four_tables): occurrences that end anywhere in a dword, at every boundary, dense and overlapping ones,
-    text bytes that are none of the pattern's symbols (the dword then takes its byte steps), symbols that are not 0..3
-    (ACGT), windows beyond 62 bytes (the prefix's automaton + verification) — against the oracle, with the table and
-    without it (tune(3,5): round 2's kernel on the same tables)."""
+    """kmp_runs on a text of at most four distinct byte values takes four text bytes per table step (kmp_runs<.., FOUR>:
+    the rows 4s + 2, which the workgroup derives from the byte table with the text's own two-bit codes): occurrences
+    that end anywhere in a dword, at every boundary, dense and overlapping ones, symbols that are not 0..3 (ACGT),
+    patterns over fewer symbols than the text, windows beyond 62 bytes (the prefix's automaton + verification), a text
+    that ALSO holds a fifth value (the byte-wise kernel on the same plan) — against the oracle, with the table and
+    without it (tune(3,5))."""
     from smart_amd import engine
     rng = np.random.default_rng(6)
     n = 3 << 20
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    for sigma, letters, m in ((2, None, 9), (2, None, 16), (4, None, 33), (4, acgt, 62), (4, acgt, 63), (2, None, 254), (3, None, 300), (4, acgt, 2), (2, None, 5)):
+    for sigma, letters, m, fifth in ((2, None, 9, False), (2, None, 16, False), (4, None, 33, False), (4, acgt, 62, False), (4, acgt, 63, False),
+                                     (2, None, 254, False), (3, None, 300, False), (4, acgt, 2, False), (2, None, 5, False), (4, acgt, 40, True),
+                                     (3, None, 17, True)):
         T = oracle.gen_text(777 + m, sigma, 0, n)
         if letters is not None:
             T = letters[T]
         P = T[200_000:200_000 + m].copy()
+        if m == 16:
+            P[:] = T[200_000]  # one symbol: a pattern over fewer symbols than the text, overlapping occurrences
         for k in rng.integers(0, n - m, 300):            # whole occurrences anywhere, some overlapping
             T[k:k + m] = P
-        T[rng.integers(0, n, 5000)] = 200                # bytes that are none of the pattern's symbols
+        if fifth:
+            T[rng.integers(0, n, 5000)] = 200            # a fifth value: this text is scanned a byte per step
         T[n - m:] = P
         text = Text.upload(T)
+        assert text.alphabet() == sorted(set(T.tolist())) and (len(text.alphabet()) > 4 or not fifth or sigma == 3)  # {0, 1, 2, 200}: four values no two bits separate
         want = oracle.search("kmp", P, T)
         assert want >= 100
         engine.tune(0, 1)  # KMP on its own kernel at any length
@@ -643,6 +650,7 @@ def test_kmp_four_bytes_per_step(oracle):
             got_four = smart_amd.search("kmp", P, text)[0]
             engine.tune(3, 5)
             got_plain = smart_amd.search("kmp", P, text)[0]
+            engine.tune(3, 0)
             sub = smart_amd.search("kmp", P, text, off=123_457, n=1_500_001)[0]
         finally:
             engine.tune(3, 0)
@@ -650,3 +658,85 @@ def test_kmp_four_bytes_per_step(oracle):
         assert got_four == want and got_plain == want, (sigma, m, got_four, got_plain, want)
         assert sub == oracle.search("kmp", P, T[123_457:123_457 + 1_500_001]), (sigma, m)
         text.free()
+    # a pattern over FIVE symbols on a four-symbol text (it cannot occur; the byte-wise kernel says so)
+    T = acgt[oracle.gen_text(5, 4, 0, n)]
+    text = Text.upload(T)
+    engine.tune(0, 1)
+    try:
+        assert smart_amd.search("kmp", np.frombuffer(b"ACGTNACGT", dtype=np.uint8), text)[0] == 0
+    finally:
+        engine.tune(0, 0)
+    text.free()
+
+
+def test_text_alphabet():
+    """What a text consists of is taken on the device when it is created (smartgpu_text_alphabet): uploaded, tiled and
+    generated texts, lengths that are no multiple of the 16-byte loads, the empty text."""
+    rng = np.random.default_rng(11)
+    for n, values in ((0, [0]), (1, [9]), (15, [1, 2]), (16, [255]), (17, [0, 255]), (100_003, [65, 67, 71, 84]),
+                      (1 << 20, list(range(256))), ((1 << 20) + 5, [3, 77, 200, 201, 202])):
+        T = np.asarray(values, dtype=np.uint8)[rng.integers(0, len(values), n)]
+        if n > 16:
+            T[-1] = values[-1]  # a value that may occur in the last, partial 16 bytes only
+            T[:-1][T[:-1] == values[-1]] = values[0]
+        text = Text.upload(T)
+        assert text.alphabet() == sorted(set(T.tolist())), (n, values)
+        text.free()
+    text = Text.generate(SEED2, 4, 1 << 20)
+    assert text.alphabet() == [0, 1, 2, 3]
+    text.free()
+    unit = np.frombuffer(b"abracadabra", dtype=np.uint8)
+    text = Text.upload_tiled(unit, 100_000)
+    assert text.alphabet() == sorted(set(unit.tolist()))
+    text.free()
+
+
+def test_four_symbol_texts_on_shift_or_runs(oracle):
+    """On a text of at most four distinct byte values so_runs takes four bytes per table step (so_runs<., FOUR>: the
+    text's two-bit codes index a table of ready-made four-step operands).  Alphabets that are not 0..3 (ACGT: codes from
+    bits 1-2), two values far apart, one value, three values, four values that no pair of adjacent bits separates (the
+    byte-wise kernel then); patterns with symbols the text does not hold; 30+ byte patterns (prefix + verification);
+    sub-ranges; Shift-And's complemented masks; other algorithms' short patterns, which count on so_runs — against the
+    oracle, with the table and without (tune(6,5))."""
+    from smart_amd import engine
+    rng = np.random.default_rng(12)
+    n = (3 << 20) + 77
+    cases = (("0123", [0, 1, 2, 3], True), ("ACGT", list(b"ACGT"), True), ("far", [7, 200], True), ("one", [42], True),
+             ("three", [10, 11, 13], True), ("unseparable", [0, 1, 2, 4], False), ("five", [0, 1, 2, 3, 4], False))
+    for name, values, four in cases:
+        letters = np.asarray(values, dtype=np.uint8)
+        T = letters[rng.integers(0, len(values), n)]
+        text = Text.upload(T)
+        assert text.alphabet() == sorted(values)
+        for m in (1, 2, 3, 4, 5, 8, 12, 16, 29, 30, 33, 64, 300):
+            k = int(rng.integers(0, n - m))
+            P = T[k:k + m].copy()
+            pats = [P]
+            if m >= 2:
+                Q = P.copy()
+                Q[m // 2] = 250  # a symbol the text does not hold
+                pats.append(Q)
+            if m >= 8:  # planted, overlapping copies of a periodic pattern (not in a shared text: a copy)
+                pats.append(np.resize(letters[rng.integers(0, len(values), 3)], m))
+            for P in pats:
+                want = oracle.search("bf", P, T)
+                sub_want = oracle.search("bf", P, T[100_001:100_001 + 2_000_003])
+                for algo in ("so", "sa", "hor", "bndm", "epsm", "kmp"):
+                    if smart_amd.kernel_for(algo, P) != "so_runs":
+                        continue
+                    got = smart_amd.search(algo, P, text)[0]
+                    sub = smart_amd.search(algo, P, text, off=100_001, n=2_000_003)[0]
+                    engine.tune(6, 5)
+                    try:
+                        plain = smart_amd.search(algo, P, text)[0]
+                    finally:
+                        engine.tune(6, 0)
+                    assert got == want and plain == want and sub == sub_want, (name, algo, m, got, plain, want, sub, sub_want)
+        text.free()
+    # dense periodic matches across run boundaries
+    T = np.resize(np.frombuffer(b"ACACACGT", dtype=np.uint8), n).copy()
+    text = Text.upload(T)
+    for P in (b"ACAC", b"CACACGTACACAC", b"ACACACGT" * 5):
+        P = np.frombuffer(P, dtype=np.uint8)
+        assert smart_amd.search("so", P, text)[0] == oracle.search("bf", P, T)
+    text.free()
