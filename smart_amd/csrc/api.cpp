@@ -54,6 +54,7 @@ struct DeviceCtx {
     uint8_t* pinned = nullptr;      // staging for uploads
     size_t pinned_bytes = 0;
     unsigned long long* pinned_count = nullptr;  // 8-byte readback slot
+    uint32_t* alphabet_bits = nullptr;           // device: the 256 bits text_alphabet collects
     hipEvent_t mark[2] = {nullptr, nullptr};     // smartgpu_stream_mark()
     // smartgpu_search_batch64(): one arena for the K pattern blobs and the K counts, grown when a
     // batch needs more, never per pattern; K+1 events for the per-pattern device times
@@ -89,6 +90,7 @@ DeviceCtx* device_ctx(int device)
                 return nullptr);
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d.pinned_count), 64, hipHostMallocDefault),
                 return nullptr);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.alphabet_bits), 32), return nullptr);
         d.ready = true;
     }
     return &d;
@@ -173,13 +175,11 @@ smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
 // is never written again (ownership), so the answer holds for every later search, of any part of it.
 bool text_alphabet(smartgpu_text* t, DeviceCtx* d)
 {
-    uint32_t* dev = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&dev), 32) != hipSuccess) { set_error("hipMalloc of the alphabet bits failed"); return false; }
+    uint32_t* dev = d->alphabet_bits;
     hipError_t e = hipMemsetAsync(dev, 0, 32, d->stream);
     if (e == hipSuccess && t->n) e = sg::launch_text_alphabet(t->data(), t->n, dev, d->num_cus, d->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(t->alphabet, dev, 32, hipMemcpyDeviceToHost, d->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
-    hipFree(dev);
     if (e != hipSuccess) { set_error("text_alphabet failed: %s", hipGetErrorString(e)); return false; }
     if (!sg::four_symbol_codes(t->alphabet, &t->four_shift, &t->four_symtab)) t->four_shift = 7;
     return true;
