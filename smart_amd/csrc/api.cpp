@@ -113,6 +113,7 @@ struct smartgpu_text {
     // — for at most four of them — their two-bit codes (ScanArgs.four_shift, four_symtab; 7: none)
     uint32_t alphabet[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t four_shift = 7, four_symtab = 0;
+    sg::TextCodes codes() const { sg::TextCodes c; c.shift = four_shift; c.symtab = four_symtab; return c; }
 };
 
 struct smartgpu_plan {
@@ -182,6 +183,12 @@ bool text_alphabet(smartgpu_text* t, DeviceCtx* d)
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     if (e != hipSuccess) { set_error("text_alphabet failed: %s", hipGetErrorString(e)); return false; }
     if (!sg::four_symbol_codes(t->alphabet, &t->four_shift, &t->four_symtab)) t->four_shift = 7;
+    // the kernels' copy: the first two words of the allocation (TextCodes, kernels.hpp)
+    const uint32_t words[2] = {t->four_shift, t->four_symtab};
+    if (hipMemcpyAsync(t->base, words, 8, hipMemcpyHostToDevice, d->stream) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) {
+        set_error("text_alphabet: writing the codes failed");
+        return false;
+    }
     return true;
 }
 
@@ -523,8 +530,6 @@ sg::ScanArgs make_args(const smartgpu_plan* p, const smartgpu_text* text, uint64
     a.so_off = p->so_off;
     a.blob = p->blob;
     a.count = p->slot_ptr(slot);
-    a.four_shift = text->four_shift;
-    a.four_symtab = text->four_symtab;
     return a;
 }
 
@@ -727,7 +732,7 @@ int smartgpu_plan_launch(smartgpu_plan* p, const smartgpu_text* text, uint64_t o
         HIP_TRY(hipEventRecord(p->ev0[slot], d->stream), return SMARTGPU_ERR_HIP);
     }
     const sg::ScanArgs a = make_args(p, text, off, n, slot);
-    HIP_TRY(sg::launch_scan(p->algo, a, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
+    HIP_TRY(sg::launch_scan(p->algo, a, d->num_cus, d->stream, text->codes()), return SMARTGPU_ERR_HIP);
     if (timed) HIP_TRY(hipEventRecord(p->ev1[slot], d->stream), return SMARTGPU_ERR_HIP);
     return SMARTGPU_OK;
 }
@@ -979,8 +984,6 @@ sg::ScanArgs batch_args(const BatchPlan& bp, const DeviceCtx* d, uint32_t m, con
     a.so_off = bp.so_off;
     a.blob = d->arena + bp.off;
     a.count = slot;
-    a.four_shift = text->four_shift;
-    a.four_symtab = text->four_symtab;
     return a;
 }
 
@@ -1007,7 +1010,7 @@ int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, u
         if (timed) HIP_TRY(hipEventRecord(d->batch_events[0], d->stream), return SMARTGPU_ERR_HIP);
         for (uint32_t k = 0; k < K; ++k) {
             const sg::ScanArgs a = batch_args(plans[k], d, m, text, off, n, d->batch_counts + k);
-            HIP_TRY(sg::launch_scan(algo, a, d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
+            HIP_TRY(sg::launch_scan(algo, a, d->num_cus, d->stream, text->codes()), return SMARTGPU_ERR_HIP);
             if (timed) HIP_TRY(hipEventRecord(d->batch_events[k + 1], d->stream), return SMARTGPU_ERR_HIP);
             if (groups_out) groups_out->push_back({k, 1u});
         }
@@ -1039,7 +1042,7 @@ int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, u
         first.blob = d->arena;
         // gridDim.y holds at most 65535: a larger group goes as several grids over slices of its items
         for (uint32_t lo = i; lo < j; lo += kOneGridMaxY)
-            HIP_TRY(sg::launch_scan_set(algo, first, dev_items + lo, std::min(kOneGridMaxY, j - lo), d->num_cus, d->stream), return SMARTGPU_ERR_HIP);
+            HIP_TRY(sg::launch_scan_set(algo, first, dev_items + lo, std::min(kOneGridMaxY, j - lo), d->num_cus, d->stream, text->codes()), return SMARTGPU_ERR_HIP);
         if (timed) HIP_TRY(hipEventRecord(d->batch_events[ev++], d->stream), return SMARTGPU_ERR_HIP);
         if (groups_out) groups_out->push_back({i, j - i});
         i = j;

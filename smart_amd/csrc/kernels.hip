@@ -45,6 +45,7 @@ namespace sg {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
 
+
 // The arguments of this workgroup: the by-value set of a single launch, or — a pattern set in one grid
 // (launch_scan_set) — that set with the per-pattern fields of element blockIdx.y of the set's item array: where
 // the pattern's tables sit in the arena, which count slot is its own, and what its plan decided.  The pointers
@@ -1447,6 +1448,9 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < kSoWindow ? m : kSoWindow;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // FOUR: the text's two-bit codes, from the first words of the text's own allocation (TextCodes, kernels.hpp)
+    const uint32_t four_shift = FOUR ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[0] : 0u;
+    const uint32_t four_symtab = FOUR ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[1] : 0u;
     uint32_t* S = reinterpret_cast<uint32_t*>(smem);
     const RunIo io = swap_io(smem + 65536 + wave * kLineSlab, lane, run_len);
     const uint32_t sh = 29u - w;
@@ -1458,7 +1462,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
         auto mask = [&](uint32_t c) { return (Sg[c] << sh) & 0x1FFFFFFFu; };
         if (threadIdx.x < 256) {
             if (FOUR) {
-                auto of_code = [&](uint32_t code) { return mask((a.four_symtab >> (8u * (code & 3u))) & 0xFFu); };
+                auto of_code = [&](uint32_t code) { return mask((four_symtab >> (8u * (code & 3u))) & 0xFFu); };
                 const uint32_t t = threadIdx.x;
                 stage[t] = (of_code(t) << 3) | (of_code(t >> 2) << 2) | (of_code(t >> 4) << 1) | of_code(t >> 6);
                 reinterpret_cast<uint32_t*>(smem + kS1)[t] = mask(t);
@@ -1526,7 +1530,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
                     for (int i = 0; i < 16; ++i) {
                         const uint4& vv = v[i >> 2];
                         const uint32_t d = (i & 3) == 0 ? vv.x : (i & 3) == 1 ? vv.y : (i & 3) == 2 ? vv.z : vv.w;
-                        const uint32_t c = (d >> a.four_shift) & 0x03030303u;
+                        const uint32_t c = (d >> four_shift) & 0x03030303u;
                         const uint32_t idx = __builtin_amdgcn_udot4(c, 0x40100401u, 0u, false);  // c0 | c1 << 2 | c2 << 4 | c3 << 6
                         t4[i] = *(const lds_u32_t*)(size_t)((idx << 8) | lane4);
                     }
@@ -1781,7 +1785,9 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     const uint32_t qbase = table_bytes;  // Q[s] = P[s..s+4) for the states kmp_chunk_skip4 covers (256 bytes)
     const uint32_t stored = (w < 63 ? w + 1 : 256u) * 256u;  // the blob's rows (tables.cpp kmp_runs_tables)
     const uint32_t thr = *reinterpret_cast<const uint32_t*>(a.blob + dfa_off + stored + 256);
-    const uint32_t shift4 = a.four_shift;
+    // FOUR: the text's two-bit codes, from the first words of the text's own allocation (TextCodes, kernels.hpp)
+    const uint32_t shift4 = FOUR ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[0] : 0u;
+    const uint32_t four_symtab = FOUR ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[1] : 0u;
     uint8_t* const slabs = smem + table_bytes + kKmpQBytes;
     const RunIo io = swap_io(slabs + wave * kLineSlab, lane, run_len);
     {
@@ -1815,7 +1821,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
             uint32_t st = 4u * s;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t c = (a.four_symtab >> (8u * ((idx >> (2 * j)) & 3u))) & 0xFFu;
+                const uint32_t c = (four_symtab >> (8u * ((idx >> (2 * j)) & 3u))) & 0xFFu;
                 st = *(const lds_u8_t*)(size_t)(((st << 8) | c) ^ st);  // kmp_delta
             }
             smem[(r << 8) | ((idx ^ r) & 255u)] = (uint8_t)(st | 2u);  // Z | 2 if an occurrence ended on the way
@@ -2541,7 +2547,7 @@ static void allow_lds(const void* kernel, size_t lds)
 
 // Shift-Or runs (so_runs; Shift-And counts on it in complemented form); the masks u32 S[256] sit at
 // a.blob + a.so_off.  shift_and / tune(6,4): the previous kernel so_runs1 (a step per byte, LineIo), A/B.
-static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus, hipStream_t stream)
+static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus, hipStream_t stream, TextCodes codes)
 {
     // bank-private table: 64 KB shared by the 16 waves of ONE workgroup per CU
     const uint32_t m = a.m;
@@ -2549,7 +2555,7 @@ static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus,
     const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin, 128);
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
-    const bool four = a.four_shift < 7 && g_tune[6] != 5;  // the text consists of at most four symbols
+    const bool four = codes.shift < 7 && g_tune[6] != 5;  // the text consists of at most four symbols
     const size_t lds = 65536 + kRunWaves * (size_t)kLineSlab + (four ? 1024 : 0);
     const uint64_t grid = runs_grid(tr.count, num_cus);
     trace_runs("so_runs", a, L, tr, grid);
@@ -2582,13 +2588,13 @@ static hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus,
     return hipGetLastError();
 }
 
-static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream)
+static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream, TextCodes codes)
 {
     const uint32_t m = a.m;
     const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));  // the transition table of kmp_runs (api.cpp build_blob)
     // four text bytes per table step: the text holds at most four byte values and the plan's window is short enough for
     // the table (a pattern over at most four symbols — any other cannot occur in such a text); tune(3,5): never (A/B)
-    const bool four = a.prefer_packed != 0 && a.four_shift < 7 && g_tune[3] != 5;
+    const bool four = a.prefer_packed != 0 && codes.shift < 7 && g_tune[3] != 5;
     uint32_t w = a.prefer_packed ? a.prefer_packed : kmp_window(m);  // bytes the automaton recognises (with that table: api.cpp); a run re-scans w-1
     const uint32_t rows = (w < 63 ? 4 * w + 2 : 256) + (four ? 2 : 0);  // up to the absorbing row Z (+ rows 4w+2, 4w+3 of the four-byte table)
 #ifdef SMARTGPU_AB
@@ -2643,13 +2649,20 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
 #endif
     {
         // tune(3,5): without the four-byte table — round 2's kernel on the same tables (A/B)
+#define SG_KMP_RUNS4(P_, F_)                                                                             \
+    do {                                                                                                 \
+        if (lds > 64 * 1024) allow_lds(reinterpret_cast<const void*>(kmp_runs<P_, F_>), lds);            \
+        hipLaunchKernelGGL((kmp_runs<P_, F_>), dim3((uint32_t)grid, g_batch.count), dim3(64 * kRunWaves), lds, stream, a, (uint32_t)L, \
+                           (uint64_t)tr.count, dfa_off, g_batch.items);                                  \
+    } while (0)
         if (four) {
-            if (m > w) SG_KMP_RUNS((kmp_runs<true, true>), dfa_off);  // beyond 62 bytes: the prefix's automaton
-            else SG_KMP_RUNS((kmp_runs<false, true>), dfa_off);
+            if (m > w) SG_KMP_RUNS4(true, true);  // beyond 62 bytes: the prefix's automaton
+            else SG_KMP_RUNS4(false, true);
         } else {
-            if (m > w) SG_KMP_RUNS((kmp_runs<true, false>), dfa_off);  // beyond 254 bytes (62 with the four-byte table's window)
-            else SG_KMP_RUNS((kmp_runs<false, false>), dfa_off);
+            if (m > w) SG_KMP_RUNS4(true, false);  // beyond 254 bytes (62 with the four-byte table's window)
+            else SG_KMP_RUNS4(false, false);
         }
+#undef SG_KMP_RUNS4
     }
 #undef SG_KMP_RUNS
     return hipGetLastError();
@@ -2751,7 +2764,7 @@ ScanArgs prepare_scan_args(int algo, ScanArgs a)
     return a;
 }
 
-hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t stream)
+hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t stream, TextCodes codes)
 {
     if (a_in.s_end <= a_in.s_begin) return hipSuccess;
     const bool rerouted = a_in.so_off != 0 && algo != SMARTGPU_SO && algo != SMARTGPU_SA;  // plans of 2-3-symbol patterns (api.cpp)
@@ -2762,7 +2775,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
     // matcher tests all four fingerprint dwords at every alignment (33-45 % on rand2, all of them).
     // The branch-free bit-parallel runs kernel does not care what the bytes are (66-70 %): plans of
     // such patterns carry Shift-Or masks as well (api.cpp build_blob) and count with it.
-    if (rerouted && g_tune[0] == 0) return launch_so_runs(a, false, num_cus, stream);
+    if (rerouted && g_tune[0] == 0) return launch_so_runs(a, false, num_cus, stream, codes);
     switch (algo) {
         case SMARTGPU_TUNEDBM:  // hor_scan<.., 0> is Tuned BM's loop (see the kernel's comment)
         case SMARTGPU_HOR: {
@@ -2938,7 +2951,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
 #endif
             // a.so_off: prepare_scan_args.  Shift-And counts in the complemented, Shift-Or form (api.cpp build_blob); its
             // own AND form (so_runs1<.., AND = true>, masks after the Shift-Or ones) is in the A/B build: tune(6,3)
-            return launch_so_runs(a, algo == SMARTGPU_SA && g_tune[6] == 3, num_cus, stream);
+            return launch_so_runs(a, algo == SMARTGPU_SA && g_tune[6] == 3, num_cus, stream, codes);
         }
         case SMARTGPU_KMP: {
 #ifdef SMARTGPU_AB
@@ -2958,7 +2971,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
 #undef SG_KMP
 #endif
             // per-lane runs streamed through LDS
-            return launch_kmp_runs(a, num_cus, stream);
+            return launch_kmp_runs(a, num_cus, stream, codes);
         }
         case SMARTGPU_EPSM: {
             return launch_packed<SMARTGPU_EPSM>(a, num_cus, stream);  // a.fp_off: prepare_scan_args
@@ -2968,11 +2981,11 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
 }
 
 hipError_t launch_scan_set(int algo, const ScanArgs& first, const BatchItem* device_items, uint32_t count, int num_cus,
-                           hipStream_t stream)
+                           hipStream_t stream, TextCodes codes)
 {
     if (count == 0) return hipSuccess;
     g_batch = {device_items, count};
-    const hipError_t e = launch_scan(algo, first, num_cus, stream);
+    const hipError_t e = launch_scan(algo, first, num_cus, stream, codes);
     g_batch = {nullptr, 1};
     return e;
 }

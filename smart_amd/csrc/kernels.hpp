@@ -46,12 +46,17 @@ struct ScanArgs {
                                 // for other algorithms when the pattern is best counted by so_runs (else 0)
     const uint8_t* blob;        // device: [pattern kPatternBytes][tables ...]
     unsigned long long* count;  // device result slot (pre-zeroed)
-    // What the TEXT consists of (api.cpp text_alphabet, taken once when the text is created): at most four distinct
-    // byte values whose bits shift, shift+1 tell them apart — four_shift < 7, four_symtab = the byte value of each
-    // two-bit code (unused codes: a byte the text does not hold) — or four_shift = 7.  The runs kernels then take
-    // four text bytes per table step (so_runs<., true>; kmp_runs<., true> when the plan's table speaks the same codes).
-    uint32_t four_shift = 7, four_symtab = 0;
 };
+
+// What the TEXT consists of (api.cpp text_alphabet, taken once when the text is created): at most four distinct byte
+// values whose bits shift, shift+1 tell them apart — shift < 7, symtab = the byte value of each two-bit code (unused
+// codes: a byte the text does not hold) — or shift = 7.  The runs kernels then take four text bytes per table step
+// (so_runs<., true>, kmp_runs<., true>).  The host picks the instantiation with this; the KERNELS read the two words
+// from the first eight bytes of the text's own allocation (its front pad, which no load of a scan reaches: the pad is
+// kXSize + 256 bytes and more).  Neither members of ScanArgs nor kernel arguments: two more words in either changed
+// the register allocation and the schedule of kernels whose source had not changed — hor_scan ran 5-6 % slower with
+// them in ScanArgs, kmp_runs<false, false> 3-9 % slower with them as its own arguments (build against build).
+struct TextCodes { uint32_t shift = 7, symtab = 0; };
 
 // One pattern of a set that runs as ONE grid (launch_scan_set): what differs from pattern to pattern.  Everything
 // else — text, range, m — and the BASES of the table arena and of the count array come from the by-value ScanArgs.
@@ -77,14 +82,14 @@ struct LaunchInfo {
 };
 
 // Enqueue the scan for `algo` on `stream`; returns hipSuccess or the launch error.
-hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream);
+hipError_t launch_scan(int algo, const ScanArgs& a, int num_cus, hipStream_t stream, TextCodes codes = TextCodes());
 ScanArgs prepare_scan_args(int algo, ScanArgs a);  // what launch_scan fills in (fp_off, so_off of SO/SA)
 // The same for a pattern set in ONE grid (gridDim.y = count): `device_items` holds the per-pattern fields in
 // device memory, `first` the common ones with blob = arena base and count = first count slot, plus the first
 // pattern's plan fields (which choose kernel and grid: all patterns of the set must agree on prefer_packed,
 // sparse and so_off != 0 — the caller groups them — and carry prepare_scan_args' fp_off / so_off).
 hipError_t launch_scan_set(int algo, const ScanArgs& first, const BatchItem* device_items, uint32_t count, int num_cus,
-                           hipStream_t stream);
+                           hipStream_t stream, TextCodes codes = TextCodes());
 // occurrence positions (extension): appends every s in [a.s_begin, a.s_end) with T[s..s+m) == P to `out`
 // (unordered, at most `cap` entries), total in a.count; the blob must be an EPSM blob
 hipError_t launch_find(const ScanArgs& a, unsigned long long* out, unsigned long long cap, int num_cus,
