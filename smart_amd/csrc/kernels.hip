@@ -930,61 +930,71 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
             x0 = lo < hi ? (uint32_t)(lo - seg) : 0u;
             x1 = lo < hi ? (uint32_t)(hi - seg) : 0u;
         }
-        bool parked = false;  // first candidate of this tile awaiting wave_verify
-        const uint8_t* parked_at = a.text;
-        uint32_t e = 32u + x0, k = 0, D = 0xFFFFFFFFu;
-        const uint32_t ehi = 32u + x1;
-        while (e < ehi) {
-            // the window's next Q bytes, T[e-k-Q+1 .. e-k]: byte Q-1 of X is the one bndm.c:50 reads first (right to left)
-            uint32_t xw[2] = {0u, 0u};
-            {
-                const uint32_t pl = e - k - (Q - 1);  // position of the lowest of them
-                const uint32_t at = col4 + (pl >> 2) * CT::RS;
-                if (Q == 1) {
-                    xw[0] = smem[at + (pl & 3u)];
-                } else {
-                    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(smem + at);
-                    const uint32_t w1 = *reinterpret_cast<const uint32_t*>(smem + at + CT::RS);
-                    xw[0] = __builtin_amdgcn_alignbyte(w1, w0, pl);
-                    if (Q == 8) {
-                        const uint32_t w2 = *reinterpret_cast<const uint32_t*>(smem + at + 2 * CT::RS);
-                        xw[1] = __builtin_amdgcn_alignbyte(w2, w1, pl);
-                    }
-                }
-            }
-            uint32_t G = 0xFFFFFFFFu;
-#pragma unroll
-            for (int j = 0; j < Q; ++j) {  // step j reads byte Q-1-j; its mask meets D after Q-1-j more shifts
-                const int i = Q - 1 - j;
-                const uint32_t c = (xw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                G &= B[c] << i;
-            }
-            const uint32_t tt = (D << (Q - 1)) & G;  // bndm.c:51, Q times
-            const uint32_t kq = k + Q;
-            const bool occ = (int32_t)tt < 0 && kq == w;  // bndm.c:55: all w bytes are read and the factor alive is P[0..w) itself
-            D = tt << 1;                                  // bndm.c:57
-            const bool done = D == 0;  // no factor alive, or the window is read through
-            if (!LONG) {
-                hits += occ;
-            } else if (__any(occ)) {  // rare, wave-uniform: the 32-byte prefix matched, verify P[32..m) (bndm.c:99-102)
-                if (occ) {
-                    const uint8_t* rest = a.text + seg + (e - 32u) + 1;  // = text + s + w; inside the text because s < s_end
-                    if (!parked) {
-                        parked = true;
-                        parked_at = rest;
+        // The lane's walk over its window ends.  HOW says what an occurrence of the w-byte window costs: 0 (m <= 32) it IS
+        // an occurrence of P; 1 (LONG, the walk every tile takes) it is counted and its window end remembered — two
+        // VALU ops and no branch, where verifying on the spot put a wave-uniform test on every iteration (3 points on the
+        // m > 32 cells); 2 (LONG, the lanes that saw more than one in this tile — periodic texts) P[32..m) is compared
+        // on the spot (bndm.c:99-102).
+        uint32_t nocc = 0, last = 0;
+        auto walk = [&](auto how) {
+            constexpr int HOW = decltype(how)::value;
+            uint32_t e = 32u + x0, k = 0, D = 0xFFFFFFFFu;
+            const uint32_t ehi = 32u + x1;
+            while (e < ehi) {
+                // the window's next Q bytes, T[e-k-Q+1 .. e-k]: byte Q-1 of X is the one bndm.c:50 reads first (right to left)
+                uint32_t xw[2] = {0u, 0u};
+                {
+                    const uint32_t pl = e - k - (Q - 1);  // position of the lowest of them
+                    const uint32_t at = col4 + (pl >> 2) * CT::RS;
+                    if (Q == 1) {
+                        xw[0] = smem[at + (pl & 3u)];
                     } else {
-                        hits += global_equal(rest, a.blob + w, m - w);
+                        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(smem + at);
+                        const uint32_t w1 = *reinterpret_cast<const uint32_t*>(smem + at + CT::RS);
+                        xw[0] = __builtin_amdgcn_alignbyte(w1, w0, pl);
+                        if (Q == 8) {
+                            const uint32_t w2 = *reinterpret_cast<const uint32_t*>(smem + at + 2 * CT::RS);
+                            xw[1] = __builtin_amdgcn_alignbyte(w2, w1, pl);
+                        }
                     }
                 }
+                uint32_t G = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < Q; ++j) {  // step j reads byte Q-1-j; its mask meets D after Q-1-j more shifts
+                    const int i = Q - 1 - j;
+                    const uint32_t c = (xw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                    G &= B[c] << i;
+                }
+                const uint32_t tt = (D << (Q - 1)) & G;  // bndm.c:51, Q times
+                const uint32_t kq = k + Q;
+                const bool occ = (int32_t)tt < 0 && kq == w;  // bndm.c:55: all w bytes are read and the factor alive is P[0..w) itself
+                D = tt << 1;                                  // bndm.c:57
+                const bool done = D == 0;  // no factor alive, or the window is read through
+                if (HOW == 0) {
+                    hits += occ;
+                } else if (HOW == 1) {
+                    nocc += occ;
+                    last = occ ? e : last;
+                } else if (occ) {  // = text + s + w; inside the text because s < s_end
+                    hits += global_equal(a.text + seg + (e - 32u) + 1, a.blob + w, m - w);
+                }
+                // the window ends.  tt == 0: the kq bytes are no factor of P, the kq-1 after their first may be a prefix: move by
+                // w - (kq-1) (bndmq4.c:61); tt != 0 — its sign bit alone, or D' would not be 0 — they ARE a prefix of P: move by
+                // w - kq (bndm.c:54), by 1 after an occurrence
+                e += done ? w - kq + ((tt == 0 || kq == w) ? 1u : 0u) : 0u;
+                k = done ? 0u : kq;
+                D = done ? 0xFFFFFFFFu : D;
             }
-            // the window ends.  tt == 0: the kq bytes are no factor of P, the kq-1 after their first may be a prefix: move by
-            // w - (kq-1) (bndmq4.c:61); tt != 0 — its sign bit alone, or D' would not be 0 — they ARE a prefix of P: move by
-            // w - kq (bndm.c:54), by 1 after an occurrence
-            e += done ? w - kq + ((tt == 0 || kq == w) ? 1u : 0u) : 0u;
-            k = done ? 0u : kq;
-            D = done ? 0xFFFFFFFFu : D;
+        };
+        if (!LONG) {
+            walk(std::integral_constant<int, 0>());
+        } else {
+            walk(std::integral_constant<int, 1>());
+            if (__any(nocc != 0)) {  // rare, wave-uniform, once per tile: the 32-byte prefix matched somewhere
+                if (nocc > 1) walk(std::integral_constant<int, 2>());
+                hits += wave_verify(nocc == 1, a.text + seg + (last - 32u) + 1, a.blob + w, m - w);
+            }
         }
-        if (LONG) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
     }
     flush_hits(hits, a.count, smem);
 }
