@@ -376,36 +376,46 @@ __device__ __forceinline__ void hor_flat(const ScanArgs& a, uint64_t tile_first,
             x0 = lo < hi ? (uint32_t)(lo - seg) : 0u;
             x1 = lo < hi ? (uint32_t)(hi - seg) : 0u;
         }
-        bool parked = false;  // first candidate of this tile awaiting wave_verify
-        const uint8_t* parked_at = a.text;
-        uint32_t e = own + x0, k = 0, sh = 0;
-        const uint32_t ehi = own + x1;
-        while (e < ehi) {
-            const uint32_t c = smem[e - k];
-            const uint32_t pk = ptail[k];
-            const uint32_t t0 = bc[c];
-            sh = k == 0 ? t0 : sh;                 // hor.c:49: the shift is the window's LAST byte's
-            const bool eq = c == pk;               // hor.c:46
-            const bool full = eq && k == H;        // every byte the tile holds of the window is equal
-            bool ok = full;
-            if (LONG && __any(full)) {  // rare, wave-uniform: the rest of the window is in HBM
-                if (full) {
-                    const uint8_t* rest = a.text + seg + (e - own) - (m - 1);  // the window's first byte
-                    if (!parked) {
-                        parked = true;
-                        parked_at = rest;
-                        ok = false;  // counted by wave_verify below
-                    } else {
-                        ok = global_equal(rest, a.blob, m - 1 - H);
-                    }
+        // The lane's walk over its window ends.  HOW says what a window costs whose every byte in the tile is equal: 0 (the
+        // whole window is in the tile) it is an occurrence; 1 (LONG, the walk every tile takes) it is counted and its end
+        // remembered — Horspool's shift does not depend on where a window fails (hor.c:49), so the walk goes on at once and
+        // the rest of the window, in HBM, is compared ONCE per tile instead of being tested for on every iteration
+        // (bndm_scan); 2 (LONG, the lanes that saw more than one in this tile) the rest
+        // is compared on the spot.
+        uint32_t nocc = 0, last = 0;
+        auto walk = [&](auto how) {
+            constexpr int HOW = decltype(how)::value;
+            uint32_t e = own + x0, k = 0, sh = 0;
+            const uint32_t ehi = own + x1;
+            while (e < ehi) {
+                const uint32_t c = smem[e - k];
+                const uint32_t pk = ptail[k];
+                const uint32_t t0 = bc[c];
+                sh = k == 0 ? t0 : sh;                 // hor.c:49: the shift is the window's LAST byte's
+                const bool eq = c == pk;               // hor.c:46
+                const bool full = eq && k == H;        // every byte the tile holds of the window is equal
+                if (HOW == 0) {
+                    hits += full;
+                } else if (HOW == 1) {
+                    nocc += full;
+                    last = full ? e : last;
+                } else if (full) {  // the window's first byte: text + seg + (e - own) - (m - 1)
+                    hits += global_equal(a.text + seg + (e - own) - (m - 1), a.blob, m - 1 - H);
                 }
+                const bool on = eq && !full;
+                e += on ? 0u : sh;
+                k = on ? k + 1 : 0u;
             }
-            hits += ok;
-            const bool on = eq && !full;
-            e += on ? 0u : sh;
-            k = on ? k + 1 : 0u;
+        };
+        if (!LONG) {
+            walk(std::integral_constant<int, 0>());
+        } else {
+            walk(std::integral_constant<int, 1>());
+            if (__any(nocc != 0)) {  // rare, wave-uniform, once per tile
+                if (nocc > 1) walk(std::integral_constant<int, 2>());
+                hits += wave_verify(nocc == 1, a.text + seg + (last - own) - (m - 1), a.blob, m - 1 - H);
+            }
         }
-        if (LONG) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
     flush_hits(hits, a.count, smem);
 }
