@@ -816,53 +816,66 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_fi
             x0 = lo < hi ? (uint32_t)(lo - seg) : 0u;
             x1 = lo < hi ? (uint32_t)(hi - seg) : 0u;
         }
-        bool parked = false;  // first candidate of this tile awaiting wave_verify
-        const uint8_t* parked_at = a.text;
-        uint32_t e = own + x0, k = 0;
-        const uint32_t ehi = own + x1;
-        while (e < ehi) {
-            // m >= 2 here (launch_scan sends one-byte patterns to the packed matcher)
-            const uint32_t c = smem[e - k];
-            const uint32_t wk = walk[k];
-            const int b = (int)bc[c] - (int)k;  // bmBc[c] - m + 1 + i, i = m-1-k
-            if (!LONG) hits += k > H;
-            const bool eq = c == (wk & 0x1FFu);
-            const int g = (int)(wk >> 9);
-            uint32_t adv = eq ? 0u : (uint32_t)(g > b ? g : b);  // bm.c:89
-            uint32_t nk = eq ? k + 1 : 0u;
-            if (LONG && __any(nk > H)) {  // rare, wave-uniform: the halo is exhausted, the rest is in HBM
-                if (nk > H) {
+        // The lane's walk over its window ends.  HOW says what happens when the halo is exhausted (LONG: the H+1 bytes the
+        // tile holds of a window are equal, the rest is in HBM): 1 (the walk every tile takes) the candidate is counted, its
+        // end remembered, and the window moves on by a shift that is safe whatever the rest says (min of gs over the
+        // positions still unchecked, from the host) — selects, no branch; the rest is compared ONCE per tile, after the
+        // walk (hor_scan's flat form, bndm_scan: DESIGN.md section 4 round 3 item 9c); 2 (the lanes that saw more than one
+        // candidate in this tile walk again) the rest is compared on the spot and the shift is bm.c:86/89's.  0: m-1 <= H,
+        // the occurrence state k = H+1 counts.
+        uint32_t nocc = 0, last = 0;
+        auto walk_tile = [&](auto how) {
+            constexpr int HOW = decltype(how)::value;
+            uint32_t e = own + x0, k = 0;
+            const uint32_t ehi = own + x1;
+            while (e < ehi) {
+                // m >= 2 here (launch_scan sends one-byte patterns to the packed matcher)
+                const uint32_t c = smem[e - k];
+                const uint32_t wk = walk[k];
+                const int b = (int)bc[c] - (int)k;  // bmBc[c] - m + 1 + i, i = m-1-k
+                if (HOW == 0) hits += k > H;
+                const bool eq = c == (wk & 0x1FFu);
+                const int g = (int)(wk >> 9);
+                uint32_t adv = eq ? 0u : (uint32_t)(g > b ? g : b);  // bm.c:89
+                uint32_t nk = eq ? k + 1 : 0u;
+                if (HOW == 1) {
+                    const bool cand = nk > H;
+                    nocc += cand;
+                    last = cand ? e : last;
+                    adv = cand ? safe : adv;
+                    nk = cand ? 0u : nk;
+                } else if (HOW == 2 && nk > H) {
                     const uint8_t* tp = a.text + seg + (e - own);  // the window's last byte
-                    if (!parked) {
-                        // park the first candidate of the tile for wave_verify; move on by a shift that is safe
-                        // whatever the outcome (min of gs over the positions still unchecked, from the host)
-                        parked = true;
-                        parked_at = tp - (m - 1);
-                        adv = safe;
+                    uint32_t kk = nk, cc = 0;
+                    bool mismatch = false;
+                    while (kk < m) {
+                        cc = tp[-(int64_t)kk];
+                        if (cc != a.blob[m - 1 - kk]) { mismatch = true; break; }
+                        ++kk;
+                    }
+                    if (!mismatch) {
+                        ++hits;
+                        adv = gs0;
                     } else {
-                        uint32_t kk = nk, cc = 0;
-                        bool mismatch = false;
-                        while (kk < m) {
-                            cc = tp[-(int64_t)kk];
-                            if (cc != a.blob[m - 1 - kk]) { mismatch = true; break; }
-                            ++kk;
-                        }
-                        if (!mismatch) {
-                            ++hits;
-                            adv = gs0;
-                        } else {
-                            const int g2 = gtab[768 + m - 1 - kk], b2 = (int)bc[cc] - (int)kk;
-                            adv = (uint32_t)(g2 > b2 ? g2 : b2);
-                        }
+                        const int g2 = gtab[768 + m - 1 - kk], b2 = (int)bc[cc] - (int)kk;
+                        adv = (uint32_t)(g2 > b2 ? g2 : b2);
                     }
                     nk = 0;
                 }
+                e += adv;
+                k = nk;
+                // (no lane leaves the loop in the occurrence state: the step that enters it does not move e)
             }
-            e += adv;
-            k = nk;
-            // (no lane leaves the loop in the occurrence state: the step that enters it does not move e)
+        };
+        if (!LONG) {
+            walk_tile(std::integral_constant<int, 0>());
+        } else {
+            walk_tile(std::integral_constant<int, 1>());
+            if (__any(nocc != 0)) {  // rare, wave-uniform, once per tile
+                if (nocc > 1) walk_tile(std::integral_constant<int, 2>());
+                hits += wave_verify(nocc == 1, a.text + seg + (last - own) - (m - 1), a.blob, m - 1 - H);
+            }
         }
-        if (LONG) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
     flush_hits(hits, a.count, smem);
 }
