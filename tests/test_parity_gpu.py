@@ -740,3 +740,44 @@ def test_four_symbol_texts_on_shift_or_runs(oracle):
         P = np.frombuffer(P, dtype=np.uint8)
         assert smart_amd.search("so", P, text)[0] == oracle.search("bf", P, T)
     text.free()
+
+
+def test_long_patterns_with_many_candidates_per_lane_on_the_skip_kernels(oracle):
+    """The long-pattern instantiations of bm_scan, hor_scan's flat form and bndm_scan count the candidates of a lane's
+    segment in the walk and verify once per tile; a lane that saw MORE than one walks its segment again and compares on the
+    spot.  Periodic texts and patterns put several candidates — occurrences and near-occurrences — into every 64-byte
+    segment: every algorithm on its own kernel (tune(0,1)), whole text and a sub-range, against the oracle."""
+    from smart_amd import engine
+    rng = np.random.default_rng(77)
+    n = 200_000 + 13
+    texts = {"a": np.full(n, ord("a"), dtype=np.uint8),
+             "ab": np.resize(np.frombuffer(b"ab", dtype=np.uint8), n),
+             "abc+noise": np.resize(np.frombuffer(b"abcabcabd", dtype=np.uint8), n).copy()}
+    texts["abc+noise"][rng.integers(0, n, 400)] = ord("x")      # near-occurrences that fail in the part verified from memory
+    english = np.frombuffer(open(os.path.join(GOLDEN, "english_excerpt.txt"), "rb").read(), dtype=np.uint8)[:n].copy()
+    texts["english+copies"] = english
+    engine.tune(0, 1)
+    try:
+        for name, T in texts.items():
+            text = Text.upload(T)
+            for m in (18, 19, 33, 40, 64, 65, 300, 1000):
+                if name == "english+copies":
+                    P = T[5000:5000 + m].copy()
+                    for k in range(20_000, 20_000 + 40 * (m + 3), m + 3):  # copies a few bytes apart, and broken ones
+                        T2 = P.copy()
+                        if (k // (m + 3)) % 3 == 0:
+                            T2[0] ^= 1  # fails at the FIRST byte: the last thing the skip loops compare
+                        T[k:k + m] = T2
+                    text.free()
+                    text = Text.upload(T)
+                else:
+                    P = T[7:7 + m].copy()
+                want = oracle.search("bf", P, T)
+                sub_want = oracle.search("bf", P, T[1234:1234 + 150_001])
+                for algo in ("hor", "bm", "bndm", "tunedbm", "bndml"):
+                    got = smart_amd.search(algo, P, text)[0]
+                    sub = smart_amd.search(algo, P, text, off=1234, n=150_001)[0]
+                    assert got == want and sub == sub_want, (name, algo, m, got, want, sub, sub_want)
+            text.free()
+    finally:
+        engine.tune(0, 0)
