@@ -1318,6 +1318,11 @@ constexpr uint64_t kRunLenMax = 16384;   // runs of at most 16 KiB (the default:
 static_assert(8 * kRunLenMax + 512 + 4200 <= kBackPad, "the loaders' over-read past the last run must stay inside the back pad");
 constexpr int kLineSlab = 64 * 64;       // LDS bytes per wave
 constexpr int kRunWaves = 16;            // one 1024-thread workgroup per CU shares the table
+// kmp_runs<., FOUR>: TWELVE.  Its four-byte rows are looked up with a random 8-bit index — bank conflicts in 40 % of its LDS
+// cycles (profiles/r03/j_pmc_four_rand4_m32.txt) — and three waves per SIMD queue less behind one another on them than four:
+// sigma = 2 / 4, m = 16 ... 1024, build against build: 12 waves -5 ... -9 % time, 10 the same, 14 +2 %, 8 +28 %; the byte-wise
+// kernels lose with fewer (rand128: so_runs +5 %, kmp_runs +11 % at 12 waves), so_runs<., FOUR> is indifferent (-1 ... +2 %).
+constexpr int kKmpFourWaves = 12;
 
 // Which group of runs a wave starts with (it then strides by the number of waves in the grid).  A text that
 // gives every wave of the grid a group: the waves of a workgroup take ADJACENT groups — one contiguous stretch
@@ -1795,10 +1800,11 @@ __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base,
 // workgroup computes these rows itself before it starts, four lookups in the byte table per entry (0.5 us), so the
 // codes are the text's own and the plan carries nothing for them.
 template <bool PREFIX, bool FOUR>  // PREFIX: the automaton of the 62-byte prefix (m > 254; FOUR: m > 62); hits are verified
-__global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
+__global__ __launch_bounds__((FOUR ? kKmpFourWaves : kRunWaves) * 64) void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
                                                            uint32_t dfa_off, const BatchItem* __restrict__ batch)
 {
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    constexpr int kW = FOUR ? kKmpFourWaves : kRunWaves;  // waves of the workgroup
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1829,7 +1835,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
         if (w < 63) {
             // the blob holds the rows of the states 0..w one after the other: row s goes to row 4s (the rows between
             // are never addressed), row Z is filled here, Q follows the table
-            for (uint32_t i = threadIdx.x; i < (w + 1) * 16; i += kRunWaves * 64) t[(i >> 4) * 64 + (i & 15u)] = g[i];
+            for (uint32_t i = threadIdx.x; i < (w + 1) * 16; i += kW * 64) t[(i >> 4) * 64 + (i & 15u)] = g[i];
             const uint32_t z4 = Z * 0x01010101u;
             if (threadIdx.x < 16) t[Z * 16 + threadIdx.x] = make_uint4(z4, z4, z4, z4);
             else if (threadIdx.x < 32) t[table_bytes / 16 + threadIdx.x - 16] = g[stored / 16 + threadIdx.x - 16];
@@ -1838,7 +1844,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
                 t[(Z + 2) * 16 + threadIdx.x - 32] = make_uint4(zz, zz, zz, zz);
             }
         } else {
-            for (uint32_t i = threadIdx.x; i < (table_bytes + 256) / 16; i += kRunWaves * 64) t[i] = g[i];
+            for (uint32_t i = threadIdx.x; i < (table_bytes + 256) / 16; i += kW * 64) t[i] = g[i];
         }
     }
     // the perm result IS the LDS address: the table sits at LDS offset 0 (no static LDS in
@@ -1849,7 +1855,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
     }
     __syncthreads();  // table visible
     if (four) {  // the rows 4s + 2: four steps of the byte table for every index of four codes
-        for (uint32_t i = threadIdx.x; i < (w + 1) * 256u; i += kRunWaves * 64) {
+        for (uint32_t i = threadIdx.x; i < (w + 1) * 256u; i += kW * 64) {
             const uint32_t s = i >> 8, idx = i & 255u, r = 4u * s + 2u;
             uint32_t st = 4u * s;
 #pragma unroll
@@ -1864,9 +1870,9 @@ __global__ __launch_bounds__(kRunWaves * 64) void kmp_runs(ScanArgs a1, uint32_t
 
     uint32_t hits = 0;
     const uint64_t run_first = a.s_begin / run_len;  // runs are cut on absolute offsets
-    const uint64_t nwaves = (uint64_t)gridDim.x * kRunWaves;
+    const uint64_t nwaves = (uint64_t)gridDim.x * kW;
     const uint32_t nlines = (run_len + w - 1 + kRunLine - 1) / kRunLine;
-    for (uint64_t g = first_group(nruns, 64, kRunWaves, wave); g * 64 < nruns; g += nwaves) {
+    for (uint64_t g = first_group(nruns, 64, kW, wave); g * 64 < nruns; g += nwaves) {
         const uint8_t* const gbase = a.text + (run_first + g * 64) * run_len + io.loff;
         uint32_t blk[8];  // a block that lies entirely past the last run re-reads block 0 (loaded, never consumed)
 #pragma unroll
@@ -2546,11 +2552,11 @@ static uint64_t balanced_run_len(uint64_t s_begin, uint64_t s_end, uint64_t per_
 // loop on its 1 MiB texts): every workgroup copies its pattern's table (up to 64 KB) before it starts, so with enough
 // patterns to fill the chip the groups are packed 16 to a workgroup — 500 patterns x 128 groups of 128-byte runs:
 // 4000 workgroups with all waves busy instead of 64000 with one (KMP 4.3 -> 0.6 us per pattern, measured).
-static uint64_t runs_grid(uint64_t nruns, int num_cus)
+static uint64_t runs_grid(uint64_t nruns, int num_cus, int waves = kRunWaves)
 {
     const uint64_t groups = (nruns + 63) / 64;
     const uint64_t spread = groups < (uint64_t)num_cus ? groups : (uint64_t)num_cus;
-    const uint64_t packed = (groups + kRunWaves - 1) / kRunWaves;
+    const uint64_t packed = (groups + waves - 1) / waves;
     uint64_t want = (2ull * num_cus + g_batch.count - 1) / g_batch.count;  // enough workgroups for two rounds of the chip
     if (want < packed) want = packed;
     return want < spread ? want : spread;
@@ -2658,16 +2664,17 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
     const size_t table = (size_t)rows * 256;
 #endif
     // one 1024-thread workgroup per CU shares the table (<= 64 KB) next to 16 x 4 KB of slabs
-    const size_t lds = table + kKmpQBytes + kRunWaves * (size_t)kLineSlab;
+    const int waves = four ? kKmpFourWaves : kRunWaves;
+    const size_t lds = table + kKmpQBytes + waves * (size_t)kLineSlab;
     // runs of 2-4 KiB: at least 8x the w-1 bytes a run re-scans, at most 8 KiB (the loader's
     // over-read past the last run stays inside the text's back pad)
     uint64_t lmin = g_tune[5] ? std::min<uint64_t>((uint64_t)g_tune[5], kRunLenMax / 2) : 2048;
     if (lmin < 8ull * (w - 1)) lmin = 8ull * (w - 1);
     const uint64_t lfloor = 2ull * (w - 1) > 128 ? 2ull * (w - 1) : 128;  // small texts: see balanced_run_len
-    const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * kRunWaves, lmin, 2 * lmin, lfloor);
+    const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * waves, lmin, 2 * lmin, lfloor);
     const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
     if (tr.count == 0) return hipSuccess;
-    const uint64_t grid = runs_grid(tr.count, num_cus);
+    const uint64_t grid = runs_grid(tr.count, num_cus, waves);
     trace_runs("kmp_runs", a, L, tr, grid);
 #define SG_KMP_RUNS(K_, OFF_)                                                                            \
     do {                                                                                                 \
@@ -2685,7 +2692,7 @@ static hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t st
 #define SG_KMP_RUNS4(P_, F_)                                                                             \
     do {                                                                                                 \
         if (lds > 64 * 1024) allow_lds(reinterpret_cast<const void*>(kmp_runs<P_, F_>), lds);            \
-        hipLaunchKernelGGL((kmp_runs<P_, F_>), dim3((uint32_t)grid, g_batch.count), dim3(64 * kRunWaves), lds, stream, a, (uint32_t)L, \
+        hipLaunchKernelGGL((kmp_runs<P_, F_>), dim3((uint32_t)grid, g_batch.count), dim3(64 * waves), lds, stream, a, (uint32_t)L, \
                            (uint64_t)tr.count, dfa_off, g_batch.items);                                  \
     } while (0)
         if (four) {
