@@ -32,7 +32,7 @@ build / the CPU oracle for the cpu_baseline sample.  A mismatch aborts the run.
 At N = 1 a per-cell sweep follows: every cell of BASELINE config 2
 (HOR/BM/KMP/SO/BNDM/EPSM x m in {4,8,32,256} on the 1 GiB rand128 text), of
 config 3 (SO, BNDM x sigma in {2,4} x m in {2..64} on 1 GiB) and of configs 4 and
-5 at 1 GiB, each timed with HIP events over >= 12 launches, with the kernel that
+5 at 1 GiB, each timed with HIP events (the median of 4 rounds of 3 patterns), with the kernel that
 ran, its fraction of the 8 TB/s HBM peak and a count check; cells whose plans
 were rerouted to another kernel are measured again on the algorithm's own kernel
 (smartgpu_tune(0,1)).  The CELLS go to a file (--sweep-out, default
@@ -470,8 +470,8 @@ def run_sweep(text128, device):
     (SO and BNDM x sigma in {2,4} x m in {2,4,8,16,32,64}, 1 GiB), config 4's corpus (the English
     unit bible.txt||world192.txt tiled to 1 GiB here, six algorithms x the lengths of sets.h:25) and
     config 5's alphabets (sigma in {2,32,256} x HOR/BM/KMP/SO/EPSM x sets.h:25, one 1 GiB shard):
-    the harness loop of src/smart.c:290-345 reduced to what it times: per cell 3 patterns x 4
-    launches between two HIP events on the launch stream.  Every cell names the kernel its plans
+    the harness loop of src/smart.c:290-345 reduced to what it times: per cell 4 rounds of 3 patterns,
+    each round between two HIP events on the launch stream; a cell's time is its median round.  Every cell names the kernel its plans
     launched; a cell whose plans were rerouted (api.cpp build_blob) is measured again on the
     algorithm's own kernel."""
     import numpy as np
@@ -492,12 +492,15 @@ def run_sweep(text128, device):
             kernels = collections.Counter(pl.kernel_name for pl in plans)
             plans[0].launch(text, slot=1)  # warm-up (code object, LDS attribute)
             engine.device_sync(device)
-            engine.stream_mark(device, 0)
-            for r in range(REPS):
+            rounds = []
+            for r in range(REPS):  # every round between its own pair of events: ONE stall of the box inside a single
+                engine.stream_mark(device, 0)  # 12-launch interval read as a 58 % cell once (hor m=256, 84 % in every sweep)
                 for pl in plans:
                     pl.launch(text, slot=0)
-            engine.stream_mark(device, 1)
-            ms = engine.stream_elapsed_ms(device) / (REPS * len(plans))
+                engine.stream_mark(device, 1)
+                rounds.append(engine.stream_elapsed_ms(device) / len(plans))
+            rounds.sort()
+            ms = 0.5 * (rounds[(REPS - 1) // 2] + rounds[REPS // 2])  # the median round
             counts = [pl.result(0)[0] // REPS for pl in plans]
         finally:
             if own:
@@ -585,10 +588,10 @@ def run_sweep(text128, device):
                          "own_kernel_cells": min([c["frac"] for c in cells if c.get("own_kernel")] or [None])},
             "note": "config = BASELINE.json configuration the cell belongs to (4: the English unit tiled to 1 GiB, 5: one 1 GiB "
                     "shard per alphabet; their 4 GiB sizes: profiles/ sweeps, tests/test_configs_gpu.py); "
-                    "1 GiB per cell; ms = HIP events over %d launches (%d patterns x %d); frac = 2^30 B / ms / 8 TB/s; "
+                    "1 GiB per cell; ms = the median of %d rounds, each %d patterns between two HIP events; frac = 2^30 B / ms / 8 TB/s; "
                     "own_kernel = measured again with smartgpu_tune(0,1) because the plan rerouted the pattern; "
                     "count_ok = equal to the count of a kernel of another family (reference kernels used: %s)"
-                    % (J * REPS, J, REPS, dict(checked_by))}
+                    % (REPS, J, dict(checked_by))}
 
 
 if __name__ == "__main__":
