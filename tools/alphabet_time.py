@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Wall time of creating a 1 GiB text on the device, generator + alphabet pass (api.cpp text_alphabet): python tools/alphabet_time.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time, numpy as np, smart_amd
