@@ -232,7 +232,9 @@ int smartgpu_probe_read_ms(const smartgpu_text *t, int reps, double *ms_per_pass
  *      loop / 2 Horspool's bank-private LDS layout / 3 always the packed matcher
  *   1  bndm_scan: bytes of a window read per iteration (1, 2, 4, 8; 0 = the plan's choice from the pattern)
  *   2  bm_scan / bndm_scan workgroups: 1 four waves / 2 two waves (0 = default: bm_scan two where the pattern's symbols
- *      repeat, bndm_scan always four)
+ *      repeat, bndm_scan always four); 3 = Horspool's nested loop also where the pattern's symbols repeat (default
+ *      there: its flat form, round 3)
+ *   4  workgroups per CU of the LDS-tile kernels (0 = the launcher's choice)
  *   3  KMP: 0 kmp_runs (transition table) / 1 kmp_scan (LDS tiles, m <= 40) / 2 kmp_links_runs
  *      (failure links followed per byte) / 5 kmp_runs a byte per table step even on a text of at most four
  *      byte values (round 3: there it takes four)
