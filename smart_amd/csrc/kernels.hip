@@ -45,6 +45,13 @@ namespace sg {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t round16(uint32_t x) { return (x + 15u) & ~15u; }
 
+// LDS by OFFSET: a kernel without static LDS has its dynamic segment at offset 0, and an integer offset as the address
+// saves the "+ base" the compiler otherwise adds to every LDS address it forms from the extern array (a v_add with a
+// relocated 0); the kernels that do this check the base once and poison the count if it is not 0.
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
+
 
 // The arguments of this workgroup: the by-value set of a single launch, or — a pattern set in one grid
 // (launch_scan_set) — that set with the per-pattern fields of element blockIdx.y of the set's item array: where
@@ -342,6 +349,10 @@ __device__ __forceinline__ void hor_flat(const ScanArgs& a, uint64_t tile_first,
     uint8_t* txt = smem + kTxt;
     for (uint32_t i = threadIdx.x; i < 256; i += THREADS) bc[i] = reinterpret_cast<const uint16_t*>(a.blob + kTableOff)[i] & 0x7FFFu;
     for (uint32_t k = threadIdx.x; k < 32; k += THREADS) ptail[k] = k <= H ? a.blob[m - 1 - k] : 0;
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {  // the walk below addresses LDS by offset
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
+        return;
+    }
 
     const uint64_t e_begin = a.s_begin + m - 1, e_end = a.s_end + m - 1;
     uint32_t hits = 0;
@@ -388,9 +399,9 @@ __device__ __forceinline__ void hor_flat(const ScanArgs& a, uint64_t tile_first,
             uint32_t e = own + x0, k = 0, sh = 0;
             const uint32_t ehi = own + x1;
             while (e < ehi) {
-                const uint32_t c = smem[e - k];
-                const uint32_t pk = ptail[k];
-                const uint32_t t0 = bc[c];
+                const uint32_t c = *(const lds_u8_t*)(size_t)(e - k);       // smem[e - k]
+                const uint32_t pk = *(const lds_u8_t*)(size_t)(512u + k);   // ptail[k]
+                const uint32_t t0 = *(const lds_u16_t*)(size_t)(2u * c);    // bc[c]
                 sh = k == 0 ? t0 : sh;                 // hor.c:49: the shift is the window's LAST byte's
                 const bool eq = c == pk;               // hor.c:46
                 const bool full = eq && k == H;        // every byte the tile holds of the window is equal
@@ -1275,8 +1286,6 @@ __global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a1, uint64_t tile
     flush_hits(hits, a.count, smem);
 }
 
-typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
 
 // delta[st][c]: one v_perm_b32 builds st*256 + c; the row of state st is stored XOR-swizzled,
 // delta[st][c] at st*256 + (c ^ st), which costs one v_xor: every row starts on LDS bank 0, so on
