@@ -792,6 +792,10 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_fi
     const uint32_t safe = gtab[768 + m];  // for a parked window (api.cpp build_blob)
     for (uint32_t k = threadIdx.x; k <= H + 1; k += THREADS)
         walk[k] = k <= H ? ((uint32_t)gtab[768 + m - 1 - k] << 9) | a.blob[m - 1 - k] : (gs0 << 9) | 0x100u;
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {  // the walk below addresses LDS by offset
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
+        return;
+    }
 
     const uint64_t e_begin = a.s_begin + m - 1, e_end = a.s_end + m - 1;
     uint32_t hits = 0;
@@ -841,9 +845,9 @@ __global__ __launch_bounds__(THREADS) void bm_scan(ScanArgs a1, uint64_t tile_fi
             const uint32_t ehi = own + x1;
             while (e < ehi) {
                 // m >= 2 here (launch_scan sends one-byte patterns to the packed matcher)
-                const uint32_t c = smem[e - k];
-                const uint32_t wk = walk[k];
-                const int b = (int)bc[c] - (int)k;  // bmBc[c] - m + 1 + i, i = m-1-k
+                const uint32_t c = *(const lds_u8_t*)(size_t)(e - k);          // smem[e - k]
+                const uint32_t wk = *(const lds_u32_t*)(size_t)(512u + 4u * k);  // walk[k]
+                const int b = (int)*(const lds_u16_t*)(size_t)(2u * c) - (int)k;  // bc[c] - k = bmBc[c] - m + 1 + i, i = m-1-k
                 if (HOW == 0) hits += k > H;
                 const bool eq = c == (wk & 0x1FFu);
                 const int g = (int)(wk >> 9);
