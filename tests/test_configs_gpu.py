@@ -122,6 +122,60 @@ def test_config5_shard_at_full_size(oracle, sigma):
     text.free()
 
 
+@pytest.mark.parametrize("sigma", [2, 32, 256])
+def test_config5_at_32gib_on_one_gpu(oracle, sigma):
+    """BASELINE config 5 at its STATED size — 2^35 bytes of rand-sigma — resident on ONE MI355X (288 GB).  The
+    reference cannot hold such a text at all (`int TSIZE`, src/smart.c:416,454; `int n`, main.h:39), so parity at
+    this size rests on the size-independent properties: the five named algorithms (five kernel families) agree on
+    the whole text, the eight 4 GiB shards of the configuration with their (m-1)-byte overlap sum to the whole,
+    32 MiB slices — around the planted pattern and straddling every multiple of 2^32 — equal the oracle, and the
+    window cut at n-m is found.  Start offsets beyond 2^33 and (sigma 2, m 2) a count beyond 2^32 are exercised."""
+    n = 1 << 35
+    sl = 32 << 20
+    text = Text.generate(SEED2, sigma, n)
+    assert len(text) == n
+    # the generator is counter-based: the device's bytes beyond 2^32 / 2^34 are the oracle's
+    for lo in (0, (1 << 32) - 2048, (1 << 34) + 12345, n - 4096):
+        assert np.array_equal(text.read(lo, 4096), oracle.gen_text(SEED2, sigma, lo, 4096)), lo
+    for j, m in enumerate((2, 32, 4096)):
+        k = (1 << 33) + oracle.splitmix64(0x0A77E2 + 4096 * j + m) % (n - (1 << 33) - m)  # planted beyond 2^33
+        assert k >= 1 << 33
+        P = text.pattern(k, m)
+        got = counts(P, text, CONFIG5)
+        assert len(set(got.values())) == 1 and got["hor"] >= 1, (sigma, m, got)
+        whole = got["hor"]
+        if sigma == 2 and m == 2:
+            assert whole > 1 << 32  # a quarter of all start positions: the count itself needs 64 bits
+        for a in ("hor", "kmp", "so"):  # tile kernels and the runs kernels cut the text differently
+            assert shard_sum(a, P, text, n, parts=8) == whole, (a, sigma, m)
+        # the planted copy and every 2^32 boundary inside a 32 MiB slice, against the oracle (two algorithms of the
+        # oracle per slice: the restated Horspool and brute force, the definition of truth, bf.c:25-39)
+        los = [(k - sl // 2) & ~4095] + [(b << 32) - sl // 2 - 4096 * b for b in range(1, 8)]
+        for lo in los:
+            lo = max(0, min(lo, n - sl))
+            T = text.read(lo, sl)
+            want = oracle.search("hor", P, T)
+            assert want == oracle.search("bf", P, T)
+            for a in CONFIG5:
+                assert smart_amd.search(a, P, text, off=lo, n=sl)[0] == want, (a, sigma, m, lo)
+        # a sub-range that starts beyond 2^34 and is not aligned to anything
+        lo = (1 << 34) + 777
+        T = text.read(lo, 1 << 20)
+        assert {smart_amd.search(a, P, text, off=lo, n=1 << 20)[0] for a in CONFIG5} == {oracle.search("bf", P, T)}
+    # the window cut at n - m is a start position, n - m + 1 is not
+    for m in (2, 32, 4096):
+        P = text.pattern(n - m, m)
+        T = text.read(n - (1 << 20), 1 << 20)
+        want = oracle.search("bf", P, T)
+        assert want >= 1
+        for a in CONFIG5:
+            assert smart_amd.search(a, P, text, off=n - (1 << 20), n=1 << 20)[0] == want, (a, m)
+            assert smart_amd.search(a, P, text, off=n - m, n=m)[0] == 1, (a, m)
+            if m > 2:
+                assert smart_amd.search(a, P, text, off=n - m + 1, n=m - 1)[0] == 0, (a, m)
+    text.free()
+
+
 @pytest.mark.parametrize("sigma", [4, 2])
 def test_config3_at_full_size(oracle, sigma):
     """BASELINE config 3: Shift-Or and BNDM, m <= 64, 1 GiB of sigma 4 ("genome") and sigma 2 — on the plans'
