@@ -59,7 +59,6 @@ PATTERN_SALT = 0x0A77E2  # k_j = splitmix64(PATTERN_SALT + 4096*j + m) mod (n-m)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 OWN_KERNEL = {"hor": "hor_scan", "bm": "bm_scan", "kmp": "kmp_runs", "so": "so_runs", "bndm": "bndm_scan",
               "epsm": "packed_scan"}
-KERNELS_HIP = os.path.join(ROOT, "smart_amd", "csrc", "kernels.hip")
 
 
 def splitmix64(x):
@@ -70,16 +69,18 @@ def splitmix64(x):
     return x ^ (x >> 31)
 
 
-def kernels_sha256():
-    with open(KERNELS_HIP, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()
+def kernel_sha256(kernel):
+    """sha256 of the sources that decide `kernel`'s code: its family's translation unit + the common headers
+    (smart_amd/sources.py) — not of every kernel's source."""
+    from smart_amd import sources
+    return sources.kernel_sha256(kernel)
 
 
 def load_traffic(kernel, workload_key, path=None):
     """(bytes, source) — HBM bytes per launch from the committed rocprofv3 --pmc pass (profiles/),
     corrected as MI355X_MICROARCH.md §HBM prescribes.  The figure is only valid for the kernel
-    source it was profiled on: profiles/pmc_traffic.json records the sha256 of kernels.hip, and a
-    different source gives (None, why)."""
+    source it was profiled on: profiles/pmc_traffic.json records, per kernel, the sha256 of that
+    kernel FAMILY's sources (one translation unit per family), and a different source gives (None, why)."""
     path = path or os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
@@ -87,14 +88,20 @@ def load_traffic(kernel, workload_key, path=None):
     except (OSError, ValueError):
         return None, "profiles/pmc_traffic.json is missing"
     src = table.get("_source", {})
-    have = kernels_sha256()
-    if src.get("kernels_hip_sha256") != have:
-        return None, ("not measured for this kernel source: kernels.hip sha256 %s..., the PMC pass in %s was taken on %s..."
-                      % (have[:12], src.get("summary", "profiles/"), str(src.get("kernels_hip_sha256"))[:12]))
-    v = table.get(kernel, {}).get(workload_key)
+    entry = table.get(kernel)
+    if entry is None:
+        return None, "no PMC pass for %s" % kernel
+    try:
+        have = kernel_sha256(kernel)
+    except KeyError:
+        return None, "no source set known for kernel %s" % kernel
+    if entry.get("_sha256") != have:
+        return None, ("not measured for this kernel source: %s's sources sha256 %s..., the PMC pass in %s was taken on %s..."
+                      % (kernel, have[:12], src.get("summary", "profiles/"), str(entry.get("_sha256"))[:12]))
+    v = entry.get(workload_key)
     if v is None:
         return None, "no PMC pass for %s / %s" % (kernel, workload_key)
-    return v, "%s @ %s (kernels.hip sha256 %s...)" % (src.get("summary", "profiles/"), src.get("commit", "?"), have[:12])
+    return v, "%s @ %s (%s sources sha256 %s...)" % (src.get("summary", "profiles/"), src.get("commit", "?"), kernel, have[:12])
 
 
 def launch_ranks(n):

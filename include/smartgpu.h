@@ -22,6 +22,10 @@
  * are no C++ or torch types in any signature.  The library is single-threaded
  * from the caller's point of view (like SMART); every call that returns a count
  * is synchronous.  Errors: negative return codes, text in smartgpu_last_error().
+ * Threading contract: ONE host thread per device at a time — the per-device stream, staging buffer and table arena are
+ * shared by every call on that device (src/smart.c is single-threaded); last_error / last_times are
+ * thread-local.  Loading the library sets HSA_ENABLE_IPC_MODE_LEGACY=0 (unless the environment already has it) so that
+ * RCCL works on hosts that only support dmabuf IPC: load it before the process makes its first HIP call.
  *
  * There is no CPU fallback: without a usable HIP device every compute entry
  * point fails with SMARTGPU_ERR_HIP.

@@ -54,7 +54,6 @@ struct DeviceCtx {
     uint8_t* pinned = nullptr;      // staging for uploads
     size_t pinned_bytes = 0;
     unsigned long long* pinned_count = nullptr;  // 8-byte readback slot
-    uint32_t* alphabet_bits = nullptr;           // device: the 256 bits text_alphabet collects
     hipEvent_t mark[2] = {nullptr, nullptr};     // smartgpu_stream_mark()
     // smartgpu_search_batch64(): one arena for the K pattern blobs and the K counts, grown when a
     // batch needs more, never per pattern; K+1 events for the per-pattern device times
@@ -90,10 +89,20 @@ DeviceCtx* device_ctx(int device)
                 return nullptr);
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d.pinned_count), 64, hipHostMallocDefault),
                 return nullptr);
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.alphabet_bits), 32), return nullptr);
         d.ready = true;
     }
     return &d;
+}
+
+// hor_flat, bm_scan, bndm_scan and kmp_runs address LDS by absolute offset; a kernel that finds its dynamic segment
+// elsewhere than at offset 0 (a static __shared__ crept into it) adds 2^62 to its count and returns.  No text has
+// 2^62 start positions: such a count is reported as an error, never as a result.
+constexpr unsigned long long kPoisonedCount = 1ull << 62;
+bool count_poisoned(unsigned long long c)
+{
+    if (c < kPoisonedCount) return false;
+    set_error("a scan kernel found its LDS segment displaced (static LDS in a kernel that addresses LDS by offset): count poisoned");
+    return true;
 }
 
 double now_ms()
@@ -174,9 +183,14 @@ smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
 
 // One pass over a text that has just been written (upload, tile fill, generator): which byte values it holds.  A text
 // is never written again (ownership), so the answer holds for every later search, of any part of it.
+// The 256 bits collect in the text's OWN front pad (bytes 64..95 of the allocation — zeroed with the pad; no scan reads
+// below byte 152 of it: the pad is kXSize + 256 bytes and more), not in a per-device buffer: two threads that create
+// texts on one device cannot interleave their passes.
+constexpr size_t kAlphabetScratchOff = 64;
+static_assert(kAlphabetScratchOff + 32 <= sg::kFrontPad - (SMARTGPU_XSIZE + 256), "the scratch must lie below every byte a scan can read");
 bool text_alphabet(smartgpu_text* t, DeviceCtx* d)
 {
-    uint32_t* dev = d->alphabet_bits;
+    uint32_t* dev = reinterpret_cast<uint32_t*>(t->base + kAlphabetScratchOff);
     hipError_t e = hipMemsetAsync(dev, 0, 32, d->stream);
     if (e == hipSuccess && t->n) e = sg::launch_text_alphabet(t->data(), t->n, dev, d->num_cus, d->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(t->alphabet, dev, 32, hipMemcpyDeviceToHost, d->stream);
@@ -185,8 +199,26 @@ bool text_alphabet(smartgpu_text* t, DeviceCtx* d)
     if (!sg::four_symbol_codes(t->alphabet, &t->four_shift, &t->four_symtab)) t->four_shift = 7;
     // the kernels' copy: the first two words of the allocation (TextCodes, kernels.hpp)
     const uint32_t words[2] = {t->four_shift, t->four_symtab};
-    if (hipMemcpyAsync(t->base, words, 8, hipMemcpyHostToDevice, d->stream) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) {
+    if (hipMemcpyAsync(t->base, words, 8, hipMemcpyHostToDevice, d->stream) != hipSuccess ||
+        hipMemsetAsync(dev, 0, 32, d->stream) != hipSuccess ||  // the pad is zero again
+        hipStreamSynchronize(d->stream) != hipSuccess) {
         set_error("text_alphabet: writing the codes failed");
+        return false;
+    }
+    return true;
+}
+
+// A text that is searched ONCE (the int search(P, m, T, n) shims upload it per call): no alphabet pass — a full
+// read of the text and two synchronisations for a table form that one search does not pay back.  The runs kernels
+// then take their byte-wise forms (shift 7 = "not a four-symbol text"), which are correct on any text.
+bool text_no_alphabet(smartgpu_text* t, DeviceCtx* d)
+{
+    t->four_shift = 7;
+    t->four_symtab = 0;
+    for (uint32_t& wv : t->alphabet) wv = 0xFFFFFFFFu;  // unknown: every byte value may occur
+    const uint32_t words[2] = {7u, 0u};
+    if (hipMemcpyAsync(t->base, words, 8, hipMemcpyHostToDevice, d->stream) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) {
+        set_error("text upload: writing the codes failed");
         return false;
     }
     return true;
@@ -578,7 +610,7 @@ int smartgpu_device_sync(int device)
 }
 
 /* ---- text ------------------------------------------------------------- */
-smartgpu_text* smartgpu_text_upload(const void* host, uint64_t n, int device)
+static smartgpu_text* text_upload_impl(const void* host, uint64_t n, int device, bool alphabet)
 {
     if (!host && n) { set_error("host pointer is NULL"); return nullptr; }
     DeviceCtx* d = nullptr;
@@ -598,9 +630,11 @@ smartgpu_text* smartgpu_text_upload(const void* host, uint64_t n, int device)
         done += chunk;
     }
     hipStreamSynchronize(d->stream);
-    if (!text_alphabet(t, d)) { smartgpu_text_free(t); return nullptr; }
+    if (!(alphabet ? text_alphabet(t, d) : text_no_alphabet(t, d))) { smartgpu_text_free(t); return nullptr; }
     return t;
 }
+
+smartgpu_text* smartgpu_text_upload(const void* host, uint64_t n, int device) { return text_upload_impl(host, n, device, true); }
 
 smartgpu_text* smartgpu_text_upload_tiled(const void* unit, uint64_t unit_len, uint64_t phase,
                                           uint64_t n, int device)
@@ -745,6 +779,7 @@ int smartgpu_plan_result(smartgpu_plan* p, int slot, uint64_t* count, double* ke
     HIP_TRY(hipMemcpyAsync(d->pinned_count, p->slot_ptr(slot), sizeof(unsigned long long), hipMemcpyDeviceToHost, d->stream),
             return SMARTGPU_ERR_HIP);
     HIP_TRY(hipStreamSynchronize(d->stream), return SMARTGPU_ERR_HIP);
+    if (count_poisoned(*d->pinned_count)) return SMARTGPU_ERR_HIP;
     if (count) *count = *d->pinned_count;
     if (kernel_ms) {
         *kernel_ms = -1.0;
@@ -1017,7 +1052,14 @@ int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, u
         return SMARTGPU_OK;
     }
     // one grid per group of patterns whose plans lead to the same kernel and grid
-    auto key = [&](uint32_t k) { return (plans[k].prefer_packed ? 4u : 0u) | (plans[k].so_off ? 2u : 0u) | (plans[k].sparse ? 1u : 0u); };
+    // (the key is what launch_scan derives kernel, template arguments and grid from: prefer_packed — for KMP the window
+    // of its table —, the Shift-Or reroute, sparse, and for BNDM / BNDML the q of bndm_scan that travels as halo;
+    // a mixed set ran every BNDM pattern with the first pattern's q)
+    const bool halo_is_q = algo == SMARTGPU_BNDM || algo == SMARTGPU_BNDML;
+    auto key = [&](uint32_t k) {
+        const uint32_t pp = algo == SMARTGPU_KMP ? plans[k].prefer_packed : (plans[k].prefer_packed ? 1u : 0u);
+        return (static_cast<uint64_t>(pp) << 16) | ((halo_is_q ? plans[k].halo & 0xFFu : 0u) << 8) | (plans[k].so_off ? 2u : 0u) | (plans[k].sparse ? 1u : 0u);
+    };
     std::vector<uint32_t> order(K);
     for (uint32_t k = 0; k < K; ++k) order[k] = k;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
@@ -1081,7 +1123,10 @@ int smartgpu_search_batch64(int algo, const uint8_t* const* P, uint32_t m, uint3
             return SMARTGPU_ERR_HIP);
     HIP_TRY(hipStreamSynchronize(d->stream), return SMARTGPU_ERR_HIP);
     const double wall = now_ms() - t0;
-    for (uint32_t k = 0; k < K; ++k) counts[k] = d->pinned_counts[k];
+    for (uint32_t k = 0; k < K; ++k) {
+        if (count_poisoned(d->pinned_counts[k])) return SMARTGPU_ERR_HIP;
+        counts[k] = d->pinned_counts[k];
+    }
     if (timed) {
         const bool one_grid = !(n > kOneGridMaxText || K == 1);
         const uint32_t* ord = reinterpret_cast<const uint32_t*>(d->pinned + d->pinned_bytes - static_cast<size_t>(K) * 4);
@@ -1152,7 +1197,7 @@ static int search_host(int algo, const unsigned char* P, int m, const unsigned c
 {
     if (!P || !T || m < 1 || n < 0) return SMARTGPU_NA;
     if (m > SMARTGPU_XSIZE) return SMARTGPU_NA;
-    smartgpu_text* t = smartgpu_text_upload(T, static_cast<uint64_t>(n), 0);
+    smartgpu_text* t = text_upload_impl(T, static_cast<uint64_t>(n), 0, false);  // searched once: no alphabet pass
     if (!t) return SMARTGPU_NA;
     uint64_t c = 0;
     const int rc = smartgpu_search64(algo, P, static_cast<uint32_t>(m), t, 0, static_cast<uint64_t>(n), &c, nullptr, nullptr);
@@ -1197,9 +1242,8 @@ struct Rccl {
     bool load()
     {
         if (lib) return true;
-        // dmabuf IPC only on this pool (the legacy IPC mode fails with hipIpcGetMemHandle: invalid argument);
-        // RCCL reads it when it initialises, which is after this point
-        setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
+        // (HSA_ENABLE_IPC_MODE_LEGACY=0 — dmabuf IPC, the only mode this pool's driver supports — is an HSA runtime
+        // flag read at hsa_init: set by this library's constructor below, before any HIP call of the process can be ours)
         lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!lib) { set_error("cannot load librccl.so: %s", dlerror()); return false; }
@@ -1217,6 +1261,11 @@ struct Rccl {
     }
 };
 Rccl g_rccl;
+
+// Runs when the library is loaded, i.e. before its first HIP call: ROCr reads the flag when it initialises (hsa_init,
+// on the process's first HIP call).  A process that initialised HIP before loading this library has to set it itself
+// (bench.py and host/smart.c do so at entry); an explicit setting in the environment is never overridden.
+__attribute__((constructor)) void smartgpu_set_ipc_mode() { setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0); }
 
 }  // namespace
 
@@ -1353,6 +1402,8 @@ int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint
         HIP_TRY(hipStreamSynchronize(ctx[0]->stream), return SMARTGPU_ERR_HIP);
         for (uint32_t j = 0; j < K; ++j) total[j] = ctx[0]->pinned_counts[j];
         for (int g = 1; g < k; ++g) smartgpu_device_sync(text->devices[g]);
+        for (uint32_t j = 0; j < K; ++j)
+            if (count_poisoned(total[j])) return SMARTGPU_ERR_HIP;  // (a sum of at most 16 shards: still below 2^63)
     } else {
         for (int g = 0; g < k; ++g) {  // K-count read-backs added on the host
             // (a device listed more than once re-uploads its tables: the arena is per device)
@@ -1366,7 +1417,10 @@ int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint
             HIP_TRY(hipMemcpyAsync(d->pinned_counts, d->batch_counts, static_cast<size_t>(K) * 8, hipMemcpyDeviceToHost, d->stream),
                     return SMARTGPU_ERR_HIP);
             HIP_TRY(hipStreamSynchronize(d->stream), return SMARTGPU_ERR_HIP);
-            for (uint32_t j = 0; j < K; ++j) total[j] += d->pinned_counts[j];
+            for (uint32_t j = 0; j < K; ++j) {
+                if (count_poisoned(d->pinned_counts[j])) return SMARTGPU_ERR_HIP;
+                total[j] += d->pinned_counts[j];
+            }
         }
     }
     const double run = now_ms() - t_run;

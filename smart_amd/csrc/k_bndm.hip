@@ -1,0 +1,192 @@
+// k_bndm.hip — BNDM with q-grams on column tiles: bndm_scan
+// (one translation unit per kernel family: dev_common.hpp)
+#include "dev_common.hpp"
+#include "launch_common.hpp"
+
+namespace sg {
+
+// ---------------------------------------------------------------------------
+// BNDM with q-grams, 32-bit words like the reference  (src/algos/bndm.c:27-111; reading q bytes of a window at
+// once is bndmq2.c / bndmq4.c:29-72's idea).  w = min(m,32); tiles are indexed by the END of the w-byte (prefix) window.
+// LDS: u32 B[256] (left-aligned: B[c] << (32-w)) | column tile (ColTile)
+//
+// One flat loop over (e, k, D) — window end, bytes of the window read, the factors of P still alive — in which every
+// iteration reads the NEXT Q BYTES of the window, T[e-k-Q+1 .. e-k], with ONE unaligned LDS read, looks up their Q
+// masks and takes Q steps of bndm.c:49-58 at once (bndmq4.c:29's GRAM4):
+//     t = (D << (Q-1)) & (B[c_0] << (Q-1)) & (B[c_1] << (Q-2)) & ... & B[c_{Q-1}],   D' = t << 1
+// (Q | w: a window is read through in whole iterations).  The sign bit of t <=> the k+Q bytes read are a prefix of P —
+// all w of them: an occurrence.  D' == 0 — no factor alive, or the window read through (the masks are left-aligned: the
+// last bit leaves with the w-th step) — ends the window, and e moves by w - (k+Q) + 1: the k+Q bytes are no factor of P
+// (or all of it), the k+Q-1 after their first may be (bndmq4.c:61: i += m-q+1) — by w - (k+Q) when they are a prefix
+// of P themselves (bndm.c:54; what it remembers INSIDE a gram — a longer safe shift now and then — is not kept: the
+// masks of a gram are ANDed before anything is tested).
+// Lanes that open a window and lanes that are deep in one run the same instructions; no nested loop, no divergence
+// beyond the loop's own exit.  3Q + 14 VALU instructions and Q + 1 LDS reads per iteration.
+// Q comes from the plan (api.cpp build_blob, from the pattern's own symbol statistics): the smallest of 1, 2, 4, 8 for
+// which most windows die in their first iteration.  On a large alphabet that is 1 — one text byte, one mask, as round
+// 2's loop; English: 2; four symbols: 4; two: 8 — where a loop that reads byte by byte and tests after each walks
+// five to eight dependent LDS round trips deep into nearly every window (rand4 m = 32: 66 %, rand2: 38 %).
+// ---------------------------------------------------------------------------
+template <int THREADS, int L, bool LONG, int Q>  // LONG: m > 32, prefix hits are verified
+__global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_first,
+                                                     uint32_t ntiles, const BatchItem* __restrict__ batch)
+{
+    const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    constexpr int TB = THREADS * L;
+    using CT = ColTile<THREADS>;  // a window reaches 31 bytes back: the 32 bytes in front of every segment
+    static_assert(L == 64 && (Q == 1 || Q == 2 || Q == 4 || Q == 8), "Q divides 32: no read leaves the window's 32 bytes");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t m = a.m, w = m < 32 ? m : 32;
+    uint32_t* B = reinterpret_cast<uint32_t*>(smem);
+    constexpr uint32_t kTxt = 1024;
+    uint8_t* txt = smem + kTxt;
+
+    // masks left-aligned (B'[c] = B[c] << (32-w)): D << 1 then drops factors that can no longer become a prefix, instead
+    // of carrying dead bits above bit w-1 as bndm.c's 32-bit word does for m < 32 (the next AND clears them either way:
+    // same D & B, same count) — and "a prefix" is the sign bit
+    for (uint32_t i = threadIdx.x; i < 256; i += THREADS)
+        B[i] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[i] << (32 - w);
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {  // the walk below addresses LDS by offset
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
+        return;
+    }
+
+    const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
+    uint32_t hits = 0;
+    uint4 pre[4], ph;  // prefetch registers: 4 tile rows + (threads 0, 1) the 32 bytes in front of the tile
+    auto issue = [&](uint64_t tile0) {
+        const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
+        pre[0] = ld_stream16(src);
+        pre[1] = ld_stream16(src + THREADS * 16);
+        pre[2] = ld_stream16(src + THREADS * 32);
+        pre[3] = ld_stream16(src + THREADS * 48);
+        if (threadIdx.x < 2) ph = ld_stream16(src - 32);
+    };
+    const uint64_t t_end = tile_first + ntiles;
+    uint64_t t = tile_first + blockIdx.x;
+    issue(t * TB);
+    // the lane's column; a cursor is a byte position in it: 32 + x for byte x of the segment, 0..31 the bytes before
+    const uint32_t col4 = kTxt + CT::col(threadIdx.x) * 4u;
+    for (; t < t_end; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();
+        CT::park(txt, pre, ph);
+        __syncthreads();
+        if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
+        // window ends [x0, x1) of the lane's segment are its own
+        uint32_t x0 = 0, x1 = L;
+        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+        if (tile0 < e_begin || tile0 + TB > e_end) {  // (uniform) a tile at either end of the range
+            const uint64_t lo = seg > e_begin ? seg : e_begin;
+            const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+            x0 = lo < hi ? (uint32_t)(lo - seg) : 0u;
+            x1 = lo < hi ? (uint32_t)(hi - seg) : 0u;
+        }
+        // The lane's walk over its window ends.  HOW says what an occurrence of the w-byte window costs: 0 (m <= 32) it IS
+        // an occurrence of P; 1 (LONG, the walk every tile takes) it is counted and its window end remembered — two
+        // VALU ops and no branch, where verifying on the spot put a wave-uniform test on every iteration (3 points on the
+        // m > 32 cells); 2 (LONG, the lanes that saw more than one in this tile — periodic texts) P[32..m) is compared
+        // on the spot (bndm.c:99-102).
+        uint32_t nocc = 0, last = 0;
+        auto walk = [&](auto how) {
+            constexpr int HOW = decltype(how)::value;
+            uint32_t e = 32u + x0, k = 0, D = 0xFFFFFFFFu;
+            const uint32_t ehi = 32u + x1;
+            while (e < ehi) {
+                // the window's next Q bytes, T[e-k-Q+1 .. e-k]: byte Q-1 of X is the one bndm.c:50 reads first (right to left)
+                uint32_t xw[2] = {0u, 0u};
+                {
+                    const uint32_t pl = e - k - (Q - 1);  // position of the lowest of them
+                    const uint32_t at = col4 + (pl >> 2) * CT::RS;
+                    if (Q == 1) {
+                        xw[0] = *(const lds_u8_t*)(size_t)(at + (pl & 3u));
+                    } else {
+                        const uint32_t w0 = *(const lds_u32_t*)(size_t)at;
+                        const uint32_t w1 = *(const lds_u32_t*)(size_t)(at + CT::RS);
+                        xw[0] = __builtin_amdgcn_alignbyte(w1, w0, pl);
+                        if (Q == 8) {
+                            const uint32_t w2 = *(const lds_u32_t*)(size_t)(at + 2 * CT::RS);
+                            xw[1] = __builtin_amdgcn_alignbyte(w2, w1, pl);
+                        }
+                    }
+                }
+                uint32_t G = 0xFFFFFFFFu;
+#pragma unroll
+                for (int j = 0; j < Q; ++j) {  // step j reads byte Q-1-j; its mask meets D after Q-1-j more shifts
+                    const int i = Q - 1 - j;
+                    const uint32_t c = (xw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                    G &= *(const lds_u32_t*)(size_t)(4u * c) << i;  // B[c]
+                }
+                const uint32_t tt = (D << (Q - 1)) & G;  // bndm.c:51, Q times
+                const uint32_t kq = k + Q;
+                const bool occ = (int32_t)tt < 0 && kq == w;  // bndm.c:55: all w bytes are read and the factor alive is P[0..w) itself
+                D = tt << 1;                                  // bndm.c:57
+                const bool done = D == 0;  // no factor alive, or the window is read through
+                if (HOW == 0) {
+                    hits += occ;
+                } else if (HOW == 1) {
+                    nocc += occ;
+                    last = occ ? e : last;
+                } else if (occ) {  // = text + s + w; inside the text because s < s_end
+                    hits += global_equal(a.text + seg + (e - 32u) + 1, a.blob + w, m - w);
+                }
+                // the window ends.  tt == 0: the kq bytes are no factor of P, the kq-1 after their first may be a prefix: move by
+                // w - (kq-1) (bndmq4.c:61); tt != 0 — its sign bit alone, or D' would not be 0 — they ARE a prefix of P: move by
+                // w - kq (bndm.c:54), by 1 after an occurrence
+                e += done ? w - kq + ((tt == 0 || kq == w) ? 1u : 0u) : 0u;
+                k = done ? 0u : kq;
+                D = done ? 0xFFFFFFFFu : D;
+            }
+        };
+        if (!LONG) {
+            walk(std::integral_constant<int, 0>());
+        } else {
+            walk(std::integral_constant<int, 1>());
+            if (__any(nocc != 0)) {  // rare, wave-uniform, once per tile: the 32-byte prefix matched somewhere
+                if (nocc > 1) walk(std::integral_constant<int, 2>());
+                hits += wave_verify(nocc == 1, a.text + seg + (last - 32u) + 1, a.blob + w, m - w);
+            }
+        }
+    }
+    flush_hits(hits, a.count, smem);
+}
+
+
+// ---------------------------------------------------------------------------
+// launcher: BNDM (and BNDML's m <= 32): q bytes of a window per iteration, q = a.halo from the plan (api.cpp build_blob).
+// Workgroups per CU (26.6 KB of LDS each, six fit), measured on 1 GiB (ms): a streaming scan (a.sparse,
+// rand128 m = 16 / 32 / 256) 0.170 / 0.160 / 0.173 with FOUR (five: 0.176 / 0.178 / 0.184); where windows
+// survive — English m = 16 / 32 / 256: 0.179 / 0.179 / 0.185 with FIVE (four: 0.179 / 0.174 / 0.204, six:
+// 0.183 / 0.182 / 0.192); a small alphabet (q >= 4), rand4 m = 16 / 32, rand2 m = 32: 0.185 / 0.172 / 0.195
+// with SIX (four: 0.202 / 0.165 / 0.214).  Two-wave workgroups (tune(2,2)) were never ahead: 8 of them
+// 0.190 / 0.171 / 0.200 on the small alphabets, 0.177 / 0.172 / 0.180 on English.
+// ---------------------------------------------------------------------------
+hipError_t launch_bndm(const ScanArgs& a, int num_cus, hipStream_t stream)
+{
+    const uint32_t m = a.m, w = m < 32 ? m : 32;
+    uint32_t q = g_tune[1] ? (uint32_t)g_tune[1] : a.halo;  // tune(1, q): experiments
+    while (q > 1 && w % q) q /= 2;
+    const bool two_wave = g_tune[2] == 2;
+    const int wgs = a.sparse ? 4 : q >= 4 ? 6 : 5;
+#define SG_BNDM(T_, WGS_, Q_)                                                                            \
+    do {                                                                                                  \
+        const size_t lds = 1024 + ColTile<T_>::bytes();                                                   \
+        const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)(T_) * kBndmL);      \
+        if (m > 32) return launch_tiled(bndm_scan<T_, kBndmL, true, Q_>, a, tr, T_, lds, WGS_, num_cus, stream); \
+        return launch_tiled(bndm_scan<T_, kBndmL, false, Q_>, a, tr, T_, lds, WGS_, num_cus, stream);     \
+    } while (0)
+    if (two_wave) {
+        if (q == 8) SG_BNDM(kBndmBusyT, 2 * wgs, 8);
+        if (q == 4) SG_BNDM(kBndmBusyT, 2 * wgs, 4);
+        if (q == 2) SG_BNDM(kBndmBusyT, 2 * wgs, 2);
+        SG_BNDM(kBndmBusyT, 2 * wgs, 1);
+    }
+    if (q == 8) SG_BNDM(kBndmT, wgs, 8);
+    if (q == 4) SG_BNDM(kBndmT, wgs, 4);
+    if (q == 2) SG_BNDM(kBndmT, wgs, 2);
+    SG_BNDM(kBndmT, wgs, 1);
+#undef SG_BNDM
+}
+
+
+}  // namespace sg

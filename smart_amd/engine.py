@@ -56,6 +56,9 @@ def _load(path):
         return _loaded[path]
     if not os.path.exists(path):
         raise SmartGpuError("%s is missing: run `make -C smart_amd/csrc` (or __graft_entry__.build())" % path)
+    # dmabuf IPC (the only mode this pool's driver supports) is an HSA flag read when the process first touches HIP:
+    # set before the library — and through it ROCr — is loaded; the library's own constructor does the same for C callers
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     L = C.CDLL(path)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     sig = {

@@ -91,28 +91,42 @@ def test_latest_bench_line_agrees_with_its_rocprof_summary():
 
 
 def test_splitmix_and_traffic_table(tmp_path):
-    """roofline.traffic is bound to the kernel source it was profiled on: the table records the sha256 of
-    kernels.hip, and bench.py reports null (and why) for any other source."""
+    """roofline.traffic is bound to the kernel source it was profiled on: the table records, per kernel, the sha256
+    of that kernel FAMILY's sources (one translation unit per family: smart_amd/sources.py), and bench.py reports
+    null (and why) for any other source — while an edit to another family's unit leaves the figure valid."""
+    from smart_amd import sources
     assert bench.splitmix64(0) == 0xE220A8397B1DCDAF  # the published first output of SplitMix64
-    table = {"_source": {"kernels_hip_sha256": bench.kernels_sha256(), "commit": "abc1234", "summary": "profiles/rXX/x.csv"},
-             "hor_scan": {"hor_m32_sigma128_gib1": 1082204320}}
+    table = {"_source": {"commit": "abc1234", "summary": "profiles/rXX/x.csv"},
+             "hor_scan": {"hor_m32_sigma128_gib1": 1082204320, "_sha256": bench.kernel_sha256("hor_scan")},
+             "kmp_runs": {"kmp_m32_sigma128_gib1": 1101216064, "_sha256": "0" * 64}}  # profiled on another kmp_runs
     f = tmp_path / "pmc_traffic.json"
     f.write_text(json.dumps(table))
     t, src = bench.load_traffic("hor_scan", "hor_m32_sigma128_gib1", path=str(f))
     assert t == 1082204320 and "abc1234" in src and "profiles/rXX/x.csv" in src
     t, why = bench.load_traffic("hor_scan", "no_such_workload", path=str(f))
     assert t is None and "no PMC pass" in why
-    table["_source"]["kernels_hip_sha256"] = "0" * 64  # profiled on another kernel source
-    f.write_text(json.dumps(table))
-    t, why = bench.load_traffic("hor_scan", "hor_m32_sigma128_gib1", path=str(f))
+    t, why = bench.load_traffic("kmp_runs", "kmp_m32_sigma128_gib1", path=str(f))
     assert t is None and "not measured for this kernel source" in why
-    # the committed table: either it matches the committed kernels.hip, or bench.py says null
-    t, src = bench.load_traffic("hor_scan", "hor_m32_sigma128_gib1")
+    t, why = bench.load_traffic("bm_scan", "bm_m32_sigma128_gib1", path=str(f))
+    assert t is None and "no PMC pass" in why
+    # the families' source sets are disjoint apart from the common headers: every unit's own file is in one set only
+    own = [f for u in sources.UNITS.values() for f in u if f.startswith("k_")]
+    assert len(own) == len(set(own)) == len(sources.UNITS)
+    assert all(os.path.exists(p) for u in sources.UNITS for p in sources.unit_files(u))
+    assert sources.kernel_sha256("hor_scan") != sources.kernel_sha256("kmp_runs")
+    # the committed table: every kernel's entry either matches its family's committed sources, or bench.py says null
     committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    if committed.get("_source", {}).get("kernels_hip_sha256") == bench.kernels_sha256():
-        assert t is not None and 1.0 <= t / 2**30 < 1.05
-    else:
-        assert t is None and src
+    for kernel, entry in committed.items():
+        if kernel.startswith("_"):
+            continue
+        for key, v in entry.items():
+            if key == "_sha256":
+                continue
+            t, src = bench.load_traffic(kernel, key)
+            if entry["_sha256"] == bench.kernel_sha256(kernel):
+                assert t == v and 1.0 <= t / 2**30 < 1.05, (kernel, key, t)
+            else:
+                assert t is None and src
 
 
 def test_plain_multi_gpu_invocation_launches_its_ranks():

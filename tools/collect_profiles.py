@@ -7,7 +7,7 @@ into profiles/<round>/<prefix>_* (tracked) and refresh profiles/pmc_traffic.json
 Writes: <prefix>_bench_default.json, <prefix>_bench_hor_m32_kernel_stats.csv (rocprofv3 --stats),
 <prefix>_bench_pmc_summary.csv (FETCH_SIZE / WRITE_SIZE per kernel, averaged over dispatches, KiB as
 reported), <prefix>_pytest_gpu.log.  profiles/pmc_traffic.json records, besides the bytes per launch,
-the sha256 of smart_amd/csrc/kernels.hip the passes were taken on and the commit: bench.py reports
+the sha256 of each kernel family's sources (smart_amd/sources.py) the passes were taken on and the commit: bench.py reports
 roofline.traffic only for that kernel source.  Refuses a session that gpu_round.sh marked failed.
 """
 import collections
@@ -80,19 +80,26 @@ def main():
                 best = (name, r[3])
         return best[0] if best else None
 
-    # the kernel source the session ran: the sha256 gpu_round.sh took on the box; a session without one is bound
-    # to the COMMITTED kernels.hip (the working tree may have moved on since the call was started)
+    # the kernel sources the session ran: the per-family sha256 gpu_round.sh took on the box (smart_amd/sources.py);
+    # a session without them is bound to the COMMITTED sources (the working tree may have moved on since the call started)
+    sys.path.insert(0, here)
+    from smart_amd import sources
     commit = subprocess.run(["git", "-C", here, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    committed = subprocess.run(["git", "-C", here, "show", "HEAD:smart_amd/csrc/kernels.hip"], capture_output=True).stdout
-    sha_file = os.path.join(src, "kernels_hip.sha256")
+
+    def committed(path):
+        rel = os.path.relpath(path, here)
+        return subprocess.run(["git", "-C", here, "show", "HEAD:" + rel], capture_output=True).stdout
+
+    head_shas = sources.all_unit_shas(read=committed)
+    sha_file = os.path.join(src, "kernel_sources.sha256.json")
     if os.path.exists(sha_file):
-        sha = open(sha_file).read().split()[0]
-        if sha != hashlib.sha256(committed).hexdigest():
-            commit += " (session ran a kernels.hip that differs from this commit's)"
+        shas = json.load(open(sha_file))
+        moved = sorted(u for u in shas if shas[u] != head_shas.get(u))
+        if moved:
+            commit += " (session ran sources of %s that differ from this commit's)" % ", ".join(moved)
     else:
-        sha = hashlib.sha256(committed).hexdigest()
-    traffic = {"_source": {"kernels_hip_sha256": sha, "commit": commit,
-                           "summary": f"profiles/{rnd}/{prefix}_bench_pmc_summary.csv"}}
+        shas = head_shas
+    traffic = {"_source": {"commit": commit, "summary": f"profiles/{rnd}/{prefix}_bench_pmc_summary.csv"}}
     for algo in sorted({r[0] for r in rows}):
         kern = scan_kernel(algo)
         if kern is None:
@@ -101,7 +108,7 @@ def main():
         name, _, variant = algo.partition("-")  # bench.py's workload key: <algo>_m<m>_sigma<s>_gib<g> / <algo>_m<m>_english_gib<g>
         key = "%s_m32_%s_gib1" % (name, variant if variant else "sigma128")
         if fe is not None and wr is not None:
-            traffic.setdefault(kern, {})[key] = int(round(2 * fe * 1024 + wr * 1024))
+            traffic.setdefault(kern, {"_sha256": shas[sources.KERNEL_UNIT[kern]]})[key] = int(round(2 * fe * 1024 + wr * 1024))
     probe = mean("hor", "probe_read", "FETCH_SIZE")
     traffic["_how"] = (
         "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --algo <a> --steps 5 "

@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 step() { echo "== $1"; shift; "$@"; rc=$?; if [ $rc -ne 0 ]; then echo "FAILED rc=$rc: session $TAG stops here"; echo failed > "$OUT/SESSION_FAILED"; exit $rc; fi; }
 rm -f "$OUT/SESSION_FAILED"
-sha256sum smart_amd/csrc/kernels.hip > "$OUT/kernels_hip.sha256"   # what roofline.traffic gets bound to (collect_profiles.py)
+python3 -c "import json; from smart_amd import sources; print(json.dumps(sources.all_unit_shas()))" > "$OUT/kernel_sources.sha256.json"   # what roofline.traffic gets bound to, per kernel family (collect_profiles.py)
 step "pytest -m gpu" bash -c "timeout -k 10 900 python -m pytest tests -m gpu -x -q > '$OUT/pytest_gpu.log' 2>&1; rc=\$?; tail -3 '$OUT/pytest_gpu.log'; exit \$rc"
 step "bench" bash -c "timeout -k 10 900 python bench.py --sweep-out '$OUT/bench_sweep.json' > '$OUT/bench.json' 2> '$OUT/bench.err'; rc=\$?; cut -c1-600 '$OUT/bench.json'; tail -3 '$OUT/bench.err'; exit \$rc"
 cd /tmp
