@@ -265,10 +265,22 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = engine.stream_elapsed_ms(local_rank) / K   # HIP events on the launch stream
 
+    group = None
     if dist is not None:
         tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         all_reduce_counts(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(tt[0]), float(tt[1])
+        # what the LIVE process group consists of (not what the environment promised): every rank's device as the
+        # runtime names it — the record proves N distinct GPUs behind the one all-reduce, or says that it was a rehearsal
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": dist.get_rank(), "local_rank": local_rank, "host": socket.gethostname(), "device": props.name,
+                "uuid": str(getattr(props, "uuid", "")), "pci": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0),
+                                                                                    getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))}
+        everyone = [None] * dist.get_world_size()
+        dist.all_gather_object(everyone, mine)
+        ids = [(e["host"], e["uuid"] or e["pci"]) for e in everyone]
+        group = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "distinct_devices": len(set(ids)),
+                 "devices": [[e["rank"], e["pci"], e["uuid"][-12:]] for e in everyone]}
 
     # ---- verification (outside the timed region) -------------------------------
     got = got.numpy().astype(np.uint64)
@@ -380,7 +392,10 @@ def main():
         traffic, traffic_source = load_traffic(main_kernel, key)
         out = {
             "metric": "GB/s text scanned per GPU (bit-exact occ count), m=32 on 1 GiB rand128",
+            # the contract's value is the WHOLE JOB (all N GPUs); the metric is quoted per GPU: value_per_gpu says that one
             "value": round(total_n * K / elapsed / 1e9, 2),
+            "value_per_gpu": round(total_n * K / elapsed / 1e9 / world, 2),
+            "aggregate": round(total_n * K / elapsed / 1e9, 2),
             "unit": "GB/s",
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(elapsed * 1e3 / K, 4),
@@ -392,7 +407,7 @@ def main():
                                   else "bible.txt||world192.txt as getText loads it (smart.c:95-138), tiled on device"),
                        "sharding": ("byte offset, (m-1) overlap, one all-reduce of the K counts over %d ranks (%s)"
                                     % (world, "RCCL" if args.backend == "nccl" else args.backend + ", rehearsal")) if world > 1 else "single GPU",
-                       "ranks": world,
+                       "ranks": group["world_size"] if group else 1,  # of the live process group
                        "pre_ms_per_pattern": round(pre_ms, 4),
                        "prewarm": "%d streaming-read passes over the text before the warm-up steps (clocks), untimed" % PREWARM_PASSES},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -403,17 +418,21 @@ def main():
                          "measured_stream_read_GBps": round(read_probe, 1),
                          "frac_of_measured_stream_read": round(achieved / read_probe, 4)},
             "cpu_baseline": cpu,
+            "rccl": group,  # N > 1: the live group — backend, world size, every rank's device (PCI id, uuid tail)
             "counts_verified": "all %d counts equal a kernel of another family (%s)%s"
                                % (K, "/".join(sorted(set(others))), " and the CPU sample" if cpu else ""),
         }
         if sweep is not None:
             out["min_frac"] = sweep["min_frac"]
             out["own_kernel_min"] = sweep["own_kernel_min"]
+            out["worst_cells"] = sweep["worst_cells"]
             out["sweep_cells"] = len(sweep["cells"])
             try:
+                body = json.dumps({"headline": out, "note": sweep["note"], "cells": sweep["cells"]})
                 with open(args.sweep_out, "w") as f:
-                    json.dump({"headline": out, "note": sweep["note"], "cells": sweep["cells"]}, f)
+                    f.write(body)
                 out["sweep_file"] = os.path.relpath(args.sweep_out, ROOT)
+                out["sweep_sha256"] = hashlib.sha256(body.encode()).hexdigest()  # a pulled copy of the file can be matched to this line
             except OSError as e:   # a read-only checkout: the summary is in the line all the same
                 out["sweep_file"] = "not written: %s" % e
         print(compact_line(out), flush=True)
@@ -432,8 +451,8 @@ def compact_line(out, limit=LINE_LIMIT):
     are never dropped."""
     out = json.loads(json.dumps(out))  # deep copy
     drops = [("roofline", "kernel_ms_per_pattern"), ("roofline", "traffic_source"), ("config", "prewarm"),
-             ("config", "corpus"), ("config", "sharding"), ("cpu_baseline", "all_cores"), ("own_kernel_min",),
-             ("roofline", "kernels_of_the_timed_plans"), ("counts_verified",), ("min_frac",)]
+             ("config", "corpus"), ("config", "sharding"), ("cpu_baseline", "all_cores"), ("rccl", "devices"), ("own_kernel_min",),
+             ("roofline", "kernels_of_the_timed_plans"), ("counts_verified",), ("worst_cells",), ("min_frac",)]
     line = json.dumps(out, separators=(",", ":"))
     for path in drops:
         if len(line) <= limit:
@@ -469,6 +488,21 @@ def own_kernel_summary(cells):
                 long_ = [c["frac"] for c in got if c["m"] >= 16]
                 entry[label] = [w["frac"], "%s/m%d" % (w["sigma"], w["m"]), min(long_) if long_ else None]
         out[algo] = entry
+    return out
+
+
+def worst_cells_summary(cells, k=3):
+    """Per BASELINE configuration the k worst cells under the plan's kernel choice and the k worst measured on the
+    algorithm's OWN kernel (cells the plan did not reroute, and the second entries of rerouted ones), each as
+    [algo, sigma, m, kernel, frac] — so that the driver's record of the line says WHICH cells set min_frac and
+    own_kernel_min, not only their values (the cells themselves are in the sweep file)."""
+    out = {}
+    for cfg in sorted({c["config"] for c in cells}):
+        mine = [c for c in cells if c["config"] == cfg]
+        plan = sorted((c for c in mine if not c.get("own_kernel")), key=lambda c: c["frac"])[:k]
+        own = sorted((c for c in mine if c["kernel"] == OWN_KERNEL.get(c["algo"]) and "kernels" not in c), key=lambda c: c["frac"])[:k]
+        row = lambda c: [c["algo"], c["sigma"], c["m"], c["kernel"].replace("_scan", "").replace("_runs", ""), c["frac"]]  # noqa: E731
+        out["config%d" % cfg] = {"plan": [row(c) for c in plan], "own": [row(c) for c in own]}
     return out
 
 
@@ -586,7 +620,7 @@ def run_sweep(text128, device):
         raise SystemExit("SWEEP COUNT MISMATCH: %s" % bad)
     north = [c["frac"] for c in cells if c["config"] == 2 and not c.get("own_kernel")]
     plan = lambda k: [c["frac"] for c in cells if c["config"] == k and not c.get("own_kernel")]  # noqa: E731
-    return {"cells": cells, "own_kernel_min": own_kernel_summary(cells),
+    return {"cells": cells, "own_kernel_min": own_kernel_summary(cells), "worst_cells": worst_cells_summary(cells),
             "min_frac": {"rand128_m4to256_plan_choice": min(north),
                          "config3_plan_choice": min(plan(3)), "config4_english_plan_choice": min(plan(4)),
                          "config5_plan_choice": min(plan(5)),

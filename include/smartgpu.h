@@ -129,6 +129,13 @@ int smartgpu_search64(int algo, const uint8_t *P, uint32_t m, const smartgpu_tex
 int smartgpu_search_batch64(int algo, const uint8_t *const *P, uint32_t m, uint32_t K, const smartgpu_text *text,
                             uint64_t off, uint64_t n, uint64_t *counts, double *pre_ms, double *run_ms,
                             double *batch_ms);
+/* The same, with EVERY pattern launched on its own between its own pair of events, whatever the text's size: run_ms[k]
+ * is then pattern k's device time alone (in the one-grid form above a group's patterns share their group's time).  What
+ * the harness uses when best / worst / standard deviation or the -tb bound are asked for: src/smart.c:320-329 times
+ * every pattern, :337-343 applies the bound per run, :347-351 derives best, worst and std from those times. */
+int smartgpu_search_batch64_each(int algo, const uint8_t *const *P, uint32_t m, uint32_t K, const smartgpu_text *text,
+                            uint64_t off, uint64_t n, uint64_t *counts, double *pre_ms, double *run_ms,
+                            double *batch_ms);
 
 /* SMART's own plugin shape, one symbol per algorithm (main.h:39).  T is a HOST
  * pointer: the text is uploaded for the call and released afterwards, so this
@@ -202,6 +209,13 @@ smartgpu_mtext *smartgpu_mtext_generate(uint64_t seed, int sigma, uint64_t n, in
 void smartgpu_mtext_free(smartgpu_mtext *t);
 uint64_t smartgpu_mtext_length(const smartgpu_mtext *t);
 int smartgpu_mtext_ngpus(const smartgpu_mtext *t);
+/* The partition itself (pure arithmetic, no device): shard g of `ngpus` over a text of n bytes owns the start positions
+ * [*begin, *begin + *own) — the shards' sizes differ by at most one byte and add up to n — and holds *held bytes from
+ * *begin on: its own and up to SMARTGPU_XSIZE - 1 of the following shards', never beyond byte n.  Any pointer may be NULL. */
+int smartgpu_mtext_partition(uint64_t n, int ngpus, int g, uint64_t *begin, uint64_t *own, uint64_t *held);
+/* Self-test of the host-thread pool that enqueues the k devices' launches of a multi-GPU search at once (no device
+ * needed): `rounds` rounds of up to k jobs, each job must run exactly once per round.  0 = passed. */
+int smartgpu_selftest_launch_pool(int k, int rounds);
 /* Searches every shard concurrently (one stream per device) and sums the shard counts.
  * reduce = SMARTGPU_REDUCE_RCCL: ncclAllReduce(sum, uint64) over the devices' streams (RCCL
  * over xGMI; the devices must be distinct), then one 8-byte read-back;

@@ -11,7 +11,12 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -49,6 +54,7 @@ constexpr int kMaxDevices = 16;
 
 struct DeviceCtx {
     bool ready = false;
+    int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 0;
     uint8_t* pinned = nullptr;      // staging for uploads
@@ -83,6 +89,7 @@ DeviceCtx* device_ctx(int device)
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device), return nullptr);
         d.num_cus = prop.multiProcessorCount;
+        d.device = device;
         HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking), return nullptr);
         d.pinned_bytes = 32u << 20;
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&d.pinned), d.pinned_bytes, hipHostMallocDefault),
@@ -333,13 +340,16 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
             append(tab.data(), tab.size() * 2);
             *halo = m - 1;  // forward halo: the automaton re-scans m-1 bytes
             blob.resize((blob.size() + 15) & ~size_t(15), 0);  // the transition table is 16-byte aligned
-            // kmp_runs: the automaton over w = kmp_window(m) bytes (the pattern, or its 62-byte prefix beyond 254) with an ABSORBING accept row Z (every transition into
-            // the accept state w leads to Z, Z leads to Z; row id(w) holds the real delta(w, .)), and the table of the
-            // four-bytes-at-a-time forms (tables.cpp)
+            // kmp_runs<., false, COMPACT> (round 4; every text that is not a four-symbol text): the automaton over
+            // kmp_compact_window(m) bytes — the pattern, or its 60-byte prefix — with an ABSORBING accept row Z (every transition
+            // into the accept state w leads to Z, Z leads to Z; row id(w) holds the real delta(w, .)) and the table of the
+            // four-bytes-at-a-time forms (tables.cpp), stored as the kernel keeps it: row s at s * 256.
+            sg::kmp_runs_tables(P, sg::kmp_compact_window(m), blob, true);
             // A pattern over at most four symbols (DNA-like alphabets): on a text that itself holds at most four byte values
-            // kmp_runs takes FOUR text bytes per table step (kmp_runs<., FOUR>; the table lives in the gaps of the byte table,
-            // whose ids are 4s up to 62 states, and is derived from it on the device) — the window is then the pattern or
-            // its 62-byte prefix; its length travels as the plan's prefer_packed field
+            // kmp_runs takes FOUR text bytes per table step (kmp_runs<., FOUR>; that table lives in the gaps of the SPREAD
+            // byte table, whose ids are 4s up to 62 states, and is derived from it on the device) — the window is then the
+            // pattern or its 62-byte prefix; its length travels as the plan's prefer_packed field (0: no such table).  Which
+            // of the two kernels runs is decided at launch, from the TEXT (TextCodes): each finds its own table.
             const uint32_t w4 = std::min<uint32_t>(m, sg::kKmpPrefix);
             uint32_t distinct4 = 0;
             {
@@ -348,7 +358,11 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
                     if (!have[P[i]]) { have[P[i]] = true; ++distinct4; }
             }
             const bool has4 = m >= 2 && distinct4 <= 4;
-            sg::kmp_runs_tables(P, has4 ? w4 : sg::kmp_window(m), blob);
+#ifdef SMARTGPU_AB
+            sg::kmp_runs_tables(P, has4 ? w4 : sg::kmp_window(m), blob);  // the A/B build: always (tune(3,6): round 3's one-workgroup form)
+#else
+            if (has4) sg::kmp_runs_tables(P, w4, blob);
+#endif
             if (has4) *prefer_packed = w4;
 #ifdef SMARTGPU_AB
             {   // kmp_runs1 (A/B build): the automaton of P[0..w), w = min(m, 255); state s is row id(s) = rotl8(s, 2),
@@ -954,29 +968,43 @@ constexpr uint64_t kOneGridMaxText = 32ull << 20;  // pattern sets over texts up
 constexpr uint32_t kOneGridMaxY = 65535;            // HIP's limit on gridDim.y: patterns per grid of the one-grid form
 constexpr uint32_t kBatchMaxPatterns = 1u << 18;    // per call (argument records and launch order of a set sit in the staging buffer's tail: 9 of its 32 MB)
 
-// Build the K blobs on the host and place them in the device's arena; pre_ms[k] = host table construction of
-// pattern k + its share of the upload.  plans[k].off = offset of blob k in the arena.
-int batch_upload(DeviceCtx* d, int algo, const uint8_t* const* P, uint32_t m, uint32_t K, std::vector<BatchPlan>& plans,
+// Build the K blobs on the host ONCE and place them in the arena of every device of `ds` (one device: a plain pattern
+// set; several: the shards of a multi-GPU text — VERDICT r3: the tables of a set were rebuilt per device, 8x the
+// preprocessing at 8 GPUs).  pre_ms[k] = host table construction of pattern k + its share of the uploads.
+// plans[k].off = offset of blob k in the arenas (the same in each).  The blobs are staged in ds[0]'s pinned buffer and
+// copied from there to every arena, each copy on its device's own stream.
+int batch_upload(const std::vector<DeviceCtx*>& ds, int algo, const uint8_t* const* P, uint32_t m, uint32_t K, std::vector<BatchPlan>& plans,
                  double* pre_ms)
 {
     static thread_local std::vector<uint8_t> blob;  // one buffer for every pattern of every set
+    DeviceCtx* const d0 = ds[0];
     std::vector<double> host_ms(K, 0.0);
     plans.resize(K);
     // the blobs of one algorithm and one length are equally long (multiples of 256): size the arena from the first
     if (!P[0]) { set_error("pattern 0 is NULL"); return SMARTGPU_ERR_ARG; }
     build_blob(blob, algo, P[0], m, &plans[0].halo, &plans[0].prefer_packed, &plans[0].sparse, &plans[0].so_off);
-    const size_t room = batch_tail_offset(d, K);  // the tail of the staging buffer holds the set's argument records and launch order
+    const size_t room = batch_tail_offset(d0, K);  // the tail of the staging buffer holds the set's argument records and launch order
     if (blob.size() > room) { set_error("a table blob of %zu bytes exceeds the staging buffer", blob.size()); return SMARTGPU_ERR_NOMEM; }
-    if (!batch_reserve(d, (blob.size() + 4096) * K + 256 + K * sizeof(sg::BatchItem), K)) return SMARTGPU_ERR_NOMEM;
+    size_t arena_min = 0;
+    for (DeviceCtx* d : ds) {
+        if (d->device != d0->device) HIP_TRY(hipSetDevice(d->device), return SMARTGPU_ERR_HIP);
+        if (!batch_reserve(d, (blob.size() + 4096) * K + 256 + K * sizeof(sg::BatchItem), K)) return SMARTGPU_ERR_NOMEM;
+        arena_min = arena_min ? std::min(arena_min, d->arena_bytes) : d->arena_bytes;
+    }
     double up_total = 0.0;
     size_t total = 0, fill = 0, fill_off = 0;  // staging holds `fill` bytes that belong at arena offset fill_off
     // the copy is waited for only where the staging buffer is filled again in this call: the launches that follow are
-    // ordered behind it on the stream, and every caller ends with a synchronisation before the buffer is reused
+    // ordered behind it on each device's stream, and every caller ends with a synchronisation before the buffer is reused
     auto flush = [&](bool more) -> bool {
         if (!fill) return true;
         const double t_up = now_ms();
-        const bool ok = hipMemcpyAsync(d->arena + fill_off, d->pinned, fill, hipMemcpyHostToDevice, d->stream) == hipSuccess &&
-                        (!more || hipStreamSynchronize(d->stream) == hipSuccess);
+        bool ok = true;
+        for (DeviceCtx* d : ds) {
+            if (ds.size() > 1) ok = ok && hipSetDevice(d->device) == hipSuccess;
+            ok = ok && hipMemcpyAsync(d->arena + fill_off, d0->pinned, fill, hipMemcpyHostToDevice, d->stream) == hipSuccess;
+        }
+        if (more || ds.size() > 1)  // several devices read ONE staging buffer: all done before the caller's own use of it
+            for (DeviceCtx* d : ds) ok = ok && hipStreamSynchronize(d->stream) == hipSuccess;
         up_total += now_ms() - t_up;
         fill_off += fill;
         fill = 0;
@@ -986,18 +1014,19 @@ int batch_upload(DeviceCtx* d, int algo, const uint8_t* const* P, uint32_t m, ui
         if (!P[k]) { set_error("pattern %u is NULL", k); return SMARTGPU_ERR_ARG; }
         const double t0 = now_ms();
         if (k) build_blob(blob, algo, P[k], m, &plans[k].halo, &plans[k].prefer_packed, &plans[k].sparse, &plans[k].so_off);
-        if (total + blob.size() + 256 + K * sizeof(sg::BatchItem) > d->arena_bytes) {  // rerouted patterns carry masks the first did not
-            set_error("batch: the table arena (%zu bytes) is too small for this pattern set", d->arena_bytes);
+        if (total + blob.size() + 256 + K * sizeof(sg::BatchItem) > arena_min) {  // rerouted patterns carry masks the first did not
+            set_error("batch: the table arena (%zu bytes) is too small for this pattern set", arena_min);
             return SMARTGPU_ERR_NOMEM;
         }
         if (fill + blob.size() > room && !flush(true)) { set_error("batch: table upload failed (%s)", hipGetErrorString(hipGetLastError())); return SMARTGPU_ERR_HIP; }
-        std::memcpy(d->pinned + fill, blob.data(), blob.size());  // straight into the staging buffer
+        std::memcpy(d0->pinned + fill, blob.data(), blob.size());  // straight into the staging buffer
         fill += blob.size();
         plans[k].off = total;
         total += blob.size();  // multiples of 256
         host_ms[k] = now_ms() - t0;
     }
     if (!flush(false)) { set_error("batch: table upload failed (%s)", hipGetErrorString(hipGetLastError())); return SMARTGPU_ERR_HIP; }
+    if (ds.size() > 1) HIP_TRY(hipSetDevice(d0->device), return SMARTGPU_ERR_HIP);
     const double up_ms = up_total / K;
     if (pre_ms)
         for (uint32_t k = 0; k < K; ++k) pre_ms[k] = host_ms[k] + up_ms;
@@ -1031,7 +1060,8 @@ sg::ScanArgs batch_args(const BatchPlan& bp, const DeviceCtx* d, uint32_t m, con
 // if per-pattern device times are wanted.  run_ms (or NULL): device time per pattern; in the one-grid form
 // a group's time divided by its patterns.
 int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, uint32_t m, const smartgpu_text* text,
-                  uint64_t off, uint64_t n, uint32_t K, bool timed, std::vector<std::pair<uint32_t, uint32_t>>* groups_out)
+                  uint64_t off, uint64_t n, uint32_t K, bool timed, std::vector<std::pair<uint32_t, uint32_t>>* groups_out,
+                  bool each = false)  // each: one launch per pattern whatever the text's size (smartgpu_search_batch64_each)
 {
     HIP_TRY(hipMemsetAsync(d->batch_counts, 0, static_cast<size_t>(K) * 8, d->stream), return SMARTGPU_ERR_HIP);
     if (timed)
@@ -1041,7 +1071,7 @@ int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, u
             d->batch_events.push_back(e);
         }
     if (groups_out) groups_out->clear();
-    if (n > kOneGridMaxText || K == 1) {
+    if (n > kOneGridMaxText || K == 1 || each) {
         if (timed) HIP_TRY(hipEventRecord(d->batch_events[0], d->stream), return SMARTGPU_ERR_HIP);
         for (uint32_t k = 0; k < K; ++k) {
             const sg::ScanArgs a = batch_args(plans[k], d, m, text, off, n, d->batch_counts + k);
@@ -1101,8 +1131,8 @@ int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, u
 
 extern "C" {
 
-int smartgpu_search_batch64(int algo, const uint8_t* const* P, uint32_t m, uint32_t K, const smartgpu_text* text,
-                            uint64_t off, uint64_t n, uint64_t* counts, double* pre_ms, double* run_ms, double* batch_ms)
+static int search_batch_impl(int algo, const uint8_t* const* P, uint32_t m, uint32_t K, const smartgpu_text* text,
+                             uint64_t off, uint64_t n, uint64_t* counts, double* pre_ms, double* run_ms, double* batch_ms, bool each)
 {
     if (!P || K < 1 || !counts) { set_error("batch: P/counts NULL or K = 0"); return SMARTGPU_ERR_ARG; }
     if (K > kBatchMaxPatterns) { set_error("batch: %u patterns in one set (at most %u)", K, kBatchMaxPatterns); return SMARTGPU_ERR_ARG; }
@@ -1111,13 +1141,13 @@ int smartgpu_search_batch64(int algo, const uint8_t* const* P, uint32_t m, uint3
     DeviceCtx* d = device_ctx(text->device);
     if (!d) return SMARTGPU_ERR_HIP;
     std::vector<BatchPlan> plans;
-    const int up = batch_upload(d, algo, P, m, K, plans, pre_ms);  // preprocessing phase
+    const int up = batch_upload({d}, algo, P, m, K, plans, pre_ms);  // preprocessing phase
     if (up != SMARTGPU_OK) return up;
     const bool timed = run_ms != nullptr;
     // searching phase: the set's launches, one read-back
     std::vector<std::pair<uint32_t, uint32_t>> groups;
     const double t0 = now_ms();
-    const int eq = batch_enqueue(d, algo, plans, m, text, off, n, K, timed, &groups);
+    const int eq = batch_enqueue(d, algo, plans, m, text, off, n, K, timed, &groups, each);
     if (eq != SMARTGPU_OK) return eq;
     HIP_TRY(hipMemcpyAsync(d->pinned_counts, d->batch_counts, static_cast<size_t>(K) * 8, hipMemcpyDeviceToHost, d->stream),
             return SMARTGPU_ERR_HIP);
@@ -1128,7 +1158,7 @@ int smartgpu_search_batch64(int algo, const uint8_t* const* P, uint32_t m, uint3
         counts[k] = d->pinned_counts[k];
     }
     if (timed) {
-        const bool one_grid = !(n > kOneGridMaxText || K == 1);
+        const bool one_grid = !(n > kOneGridMaxText || K == 1 || each);
         const uint32_t* ord = reinterpret_cast<const uint32_t*>(d->pinned + d->pinned_bytes - static_cast<size_t>(K) * 4);
         for (size_t g = 0; g < groups.size(); ++g) {
             float ms = 0.f;
@@ -1141,6 +1171,18 @@ int smartgpu_search_batch64(int algo, const uint8_t* const* P, uint32_t m, uint3
     g_last_pre_ms = pre_ms ? pre_ms[K - 1] : 0.0;
     g_last_run_ms = wall / K;
     return SMARTGPU_OK;
+}
+
+int smartgpu_search_batch64(int algo, const uint8_t* const* P, uint32_t m, uint32_t K, const smartgpu_text* text,
+                            uint64_t off, uint64_t n, uint64_t* counts, double* pre_ms, double* run_ms, double* batch_ms)
+{
+    return search_batch_impl(algo, P, m, K, text, off, n, counts, pre_ms, run_ms, batch_ms, false);
+}
+
+int smartgpu_search_batch64_each(int algo, const uint8_t* const* P, uint32_t m, uint32_t K, const smartgpu_text* text,
+                                 uint64_t off, uint64_t n, uint64_t* counts, double* pre_ms, double* run_ms, double* batch_ms)
+{
+    return search_batch_impl(algo, P, m, K, text, off, n, counts, pre_ms, run_ms, batch_ms, true);
 }
 
 /* ---- occurrence positions ------------------------------------------------- */
@@ -1279,23 +1321,91 @@ struct smartgpu_mtext {
 
 namespace {
 
+// first byte shard g of k owns (the shards' sizes differ by at most one byte; g = k: n)
+uint64_t shard_begin(uint64_t n, int k, int g) { return n / k * g + std::min<uint64_t>(g, n % k); }
+
 smartgpu_mtext* mtext_new(uint64_t n, int ngpus, const int* devices)
 {
     if (ngpus < 1 || ngpus > kMaxDevices) { set_error("ngpus %d outside [1,%d]", ngpus, kMaxDevices); return nullptr; }
     smartgpu_mtext* t = new smartgpu_mtext;
     t->n = n;
     for (int g = 0; g < ngpus; ++g) t->devices.push_back(devices ? devices[g] : g);
-    for (int g = 0; g <= ngpus; ++g) t->begin.push_back(n / ngpus * g + std::min<uint64_t>(g, n % ngpus));
+    for (int g = 0; g <= ngpus; ++g) t->begin.push_back(shard_begin(n, ngpus, g));
     return t;
 }
 
 // bytes shard g has to hold: its own starts plus XSIZE-1 bytes of the next shards
 void shard_span(const smartgpu_mtext* t, int g, uint64_t* off, uint64_t* len)
 {
-    *off = t->begin[g];
-    const uint64_t end = std::min<uint64_t>(t->n, t->begin[g + 1] + SMARTGPU_XSIZE - 1);
-    *len = end - *off;
+    uint64_t own = 0;
+    (void)smartgpu_mtext_partition(t->n, static_cast<int>(t->devices.size()), g, off, &own, len);
 }
+
+// k-1 parked host threads, one per further device of a multi-GPU search: the caller enqueues device 0's shard itself
+// while worker g enqueues device g's (one host thread enqueued the k devices' launches one after the other —
+// with one pattern on 128 MiB shards, a 28 us kernel, the launch latency of eight devices in a row was the bound).
+// The threads are created on the first multi-GPU search and parked on a condition variable between calls.
+class LaunchPool {
+public:
+    // fn(g) for g = 0 .. k-1: g = 0 on the calling thread, the others on the workers; returns when all are done
+    void run(int k, const std::function<void(int)>& fn)
+    {
+        if (k <= 1) { if (k == 1) fn(0); return; }
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            while (static_cast<int>(workers_.size()) < k - 1) {
+                const int idx = static_cast<int>(workers_.size()) + 1;
+                workers_.emplace_back([this, idx] { loop(idx); });
+            }
+            job_ = &fn;
+            active_ = k;
+            pending_ = k - 1;
+            ++gen_;
+        }
+        go_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+    ~LaunchPool()
+    {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        go_.notify_all();
+        for (std::thread& t : workers_) t.join();
+    }
+
+private:
+    void loop(int idx)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* job = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                go_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                if (idx < active_) job = job_;
+            }
+            if (!job) continue;  // this call uses fewer devices than there are workers
+            (*job)(idx);
+            std::unique_lock<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable go_, done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)>* job_ = nullptr;
+    uint64_t gen_ = 0;
+    int active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+LaunchPool g_pool;
 
 }  // namespace
 
@@ -1342,6 +1452,36 @@ void smartgpu_mtext_free(smartgpu_mtext* t)
 uint64_t smartgpu_mtext_length(const smartgpu_mtext* t) { return t ? t->n : 0; }
 int smartgpu_mtext_ngpus(const smartgpu_mtext* t) { return t ? static_cast<int>(t->devices.size()) : 0; }
 
+int smartgpu_mtext_partition(uint64_t n, int ngpus, int g, uint64_t* begin, uint64_t* own, uint64_t* held)
+{
+    if (ngpus < 1 || ngpus > kMaxDevices || g < 0 || g >= ngpus) { set_error("partition: shard %d of %d", g, ngpus); return SMARTGPU_ERR_ARG; }
+    const uint64_t b = shard_begin(n, ngpus, g), e = shard_begin(n, ngpus, g + 1);
+    if (begin) *begin = b;
+    if (own) *own = e - b;
+    if (held) *held = std::min<uint64_t>(n, e + SMARTGPU_XSIZE - 1) - b;
+    return SMARTGPU_OK;
+}
+
+int smartgpu_selftest_launch_pool(int k, int rounds)
+{
+    // every round: fn(g) adds g + 1 into a slot of its own and into a shared atomic; checks that each g in 0..k-1 ran
+    // exactly once per round, whatever k was in the round before (the pool keeps its workers between calls)
+    if (k < 1 || k > kMaxDevices || rounds < 1) { set_error("selftest: k %d, rounds %d", k, rounds); return SMARTGPU_ERR_ARG; }
+    for (int r = 0; r < rounds; ++r) {
+        const int kk = 1 + (r * 7 + k - 1) % k;  // varies between 1 and k
+        std::vector<int> ran(kk, 0);
+        std::atomic<long> sum{0};
+        g_pool.run(kk, [&](int g) { ++ran[g]; sum += g + 1; });
+        long want = 0;
+        for (int g = 0; g < kk; ++g) {
+            want += g + 1;
+            if (ran[g] != 1) { set_error("selftest: job %d of %d ran %d times in round %d", g, kk, ran[g], r); return SMARTGPU_ERR_HIP; }
+        }
+        if (sum != want) { set_error("selftest: sum %ld, want %ld", sum.load(), want); return SMARTGPU_ERR_HIP; }
+    }
+    return SMARTGPU_OK;
+}
+
 int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint32_t K, smartgpu_mtext* text, int reduce,
                              uint64_t* counts, double* pre_ms, double* batch_ms)
 {
@@ -1352,16 +1492,19 @@ int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint
     if (m < min_pattern(algo)) { set_error("%s: not applicable for m < %u", kAlgoNames[algo], min_pattern(algo)); return SMARTGPU_NA; }
     if (m < 1 || m > SMARTGPU_XSIZE) { set_error("pattern length %u outside [1,%d]", m, SMARTGPU_XSIZE); return SMARTGPU_ERR_ARG; }
     const int k = static_cast<int>(text->devices.size());
-    // preprocessing: the K tables are placed on every device (pre_ms: of the last device, they are equal work)
-    std::vector<std::vector<BatchPlan>> plans(k);
-    std::vector<DeviceCtx*> ctx(k, nullptr);
+    // preprocessing: the K tables are built ONCE on the host and copied to the arena of every (distinct) device
+    std::vector<BatchPlan> plans;
+    std::vector<DeviceCtx*> ctx(k, nullptr), uniq;
     for (int g = 0; g < k; ++g) {
         ctx[g] = device_ctx(text->devices[g]);
         if (!ctx[g]) return SMARTGPU_ERR_HIP;
-        const int up = batch_upload(ctx[g], algo, P, m, K, plans[g], pre_ms);
-        if (up != SMARTGPU_OK) return up;
+        if (std::find(uniq.begin(), uniq.end(), ctx[g]) == uniq.end()) uniq.push_back(ctx[g]);
     }
-    if (reduce == SMARTGPU_REDUCE_RCCL && text->comms.empty()) {
+    const int up = batch_upload(uniq, algo, P, m, K, plans, pre_ms);
+    if (up != SMARTGPU_OK) return up;
+    const bool distinct = reduce == SMARTGPU_REDUCE_RCCL;
+    if (distinct && static_cast<int>(uniq.size()) != k) { set_error("RCCL reduce: the %d devices of the text must be distinct", k); return SMARTGPU_ERR_ARG; }
+    if (distinct && text->comms.empty()) {
         if (!g_rccl.load()) return SMARTGPU_ERR_HIP;
         text->comms.assign(k, nullptr);
         const ncclResult_t st = g_rccl.CommInitAll(text->comms.data(), k, text->devices.data());
@@ -1375,7 +1518,6 @@ int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint
     // the one-GPU test of the shard arithmetic) shares one arena, so its shards take turns
     const double t_run = now_ms();
     std::vector<uint64_t> total(K, 0);
-    const bool distinct = reduce == SMARTGPU_REDUCE_RCCL;
     auto launch_shard = [&](int g) -> int {
         DeviceCtx* d = ctx[g];
         HIP_TRY(hipSetDevice(text->devices[g]), return SMARTGPU_ERR_HIP);
@@ -1383,12 +1525,20 @@ int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint
         const uint64_t own = text->begin[g + 1] - text->begin[g];
         const uint64_t have = smartgpu_text_length(text->shards[g]);
         const uint64_t span = std::min<uint64_t>(have, own + m - 1);
-        return batch_enqueue(d, algo, plans[g], m, text->shards[g], 0, span, K, false, nullptr);
+        return batch_enqueue(d, algo, plans, m, text->shards[g], 0, span, K, false, nullptr);
     };
     int rc = SMARTGPU_OK;
     if (distinct) {
-        for (int g = 0; g < k && rc == SMARTGPU_OK; ++g) rc = launch_shard(g);
-        if (rc != SMARTGPU_OK) return rc;
+        // the k devices' launches are enqueued by k host threads at once (LaunchPool): each sets its device, enqueues the
+        // memset and the kernel(s) of its shard; an error text travels back from the worker's thread-local slot
+        std::vector<int> rcs(k, SMARTGPU_OK);
+        std::vector<std::string> errs(k);
+        g_pool.run(k, [&](int g) {
+            rcs[g] = launch_shard(g);
+            if (rcs[g] != SMARTGPU_OK) errs[g] = g_error;
+        });
+        for (int g = 0; g < k; ++g)
+            if (rcs[g] != SMARTGPU_OK) { g_error = errs[g]; return rcs[g]; }
         // ONE collective for the whole pattern set: the K counts of every device, summed in place
         ncclResult_t st = g_rccl.GroupStart();
         for (int g = 0; g < k && st == ncclSuccess; ++g)
@@ -1406,11 +1556,6 @@ int smartgpu_msearch_batch64(int algo, const uint8_t* const* P, uint32_t m, uint
             if (count_poisoned(total[j])) return SMARTGPU_ERR_HIP;  // (a sum of at most 16 shards: still below 2^63)
     } else {
         for (int g = 0; g < k; ++g) {  // K-count read-backs added on the host
-            // (a device listed more than once re-uploads its tables: the arena is per device)
-            if (g > 0 && ctx[g] == ctx[g - 1]) {
-                const int up = batch_upload(ctx[g], algo, P, m, K, plans[g], nullptr);
-                if (up != SMARTGPU_OK) return up;
-            }
             rc = launch_shard(g);
             if (rc != SMARTGPU_OK) return rc;
             DeviceCtx* d = ctx[g];
@@ -1486,6 +1631,18 @@ int smartgpu_build_table(int which, const uint8_t* P, uint32_t m, int32_t* out, 
                 t.swap(lds);
             }
             v.assign(t.begin(), t.end());
+            break;
+        }
+        case 11: {  // kmp_runs' COMPACT tables as the kernel holds them in LDS: rows 0..w, row Z = 4(w+1), then Q and thr (272 bytes)
+            const uint32_t w = sg::kmp_compact_window(m);
+            std::vector<uint8_t> t;
+            sg::kmp_runs_tables(P, w, t, true);
+            const uint32_t Z = 4 * w + 4;
+            std::vector<uint8_t> lds((w + 2) * 256 + 272, 0);
+            std::memcpy(lds.data(), t.data(), (w + 1) * 256);
+            std::memset(&lds[(w + 1) * 256], static_cast<int>(Z), 256);
+            std::memcpy(&lds[(w + 2) * 256], &t[(w + 1) * 256], 272);
+            v.assign(lds.begin(), lds.end());
             break;
         }
         case 10: {  // the two-bit codes of the byte values in P[0..m) taken as a SET (a text's alphabet): shift, symtab; no entries: none

@@ -87,7 +87,7 @@ hipError_t launch_ab_kmp(const ScanArgs& a, int num_cus, hipStream_t stream, boo
     const bool links = g_tune[3] == 2;  // failure links
     const bool v1 = g_tune[3] == 3;     // the previous kernel (running maximum, half-line loader): its table follows kmp_runs'
     if (!links && !v1) { *handled = false; return hipSuccess; }
-    const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));  // the transition table of kmp_runs (api.cpp build_blob)
+    const uint32_t dfa_off = kmp_spread_off(m);  // the spread table of kmp_runs (api.cpp build_blob); kmp_runs1's follows it
     const uint32_t w0 = a.prefer_packed ? a.prefer_packed : kmp_window(m);
     const uint32_t dfa1_off = dfa_off + (w0 < 63 ? w0 + 1 : 256u) * 256 + kKmpQBytes;
     const uint32_t w = (links || m <= kKmpDfaMaxM) ? m : kKmpDfaMaxM;

@@ -33,12 +33,27 @@ __device__ __forceinline__ uint32_t sad_now(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
+// One transition.  C = false: the spread table of runs_common.hpp's kmp_delta (row id at id * 256).  C = true — the
+// COMPACT table of kmp_runs<., false, true>: the rows of the states 0..w and Z one after the other, row s (id 4s) at
+// s * 256 = id * 64, still XOR-swizzled by its id: delta(id, c) at (id << 6) | (c ^ id) (the ids are multiples of 4
+// up to 252, so id << 6 has no bit below 8 that c ^ id could collide with).  v_xor_b32 (its byte operand selected
+// from the text dword: SDWA) + v_lshl_or_b32 — two VALU operations on the chain, as v_perm_b32 + v_xor_b32 before.
+template <bool C>
+__device__ __forceinline__ uint32_t kmp_step(uint32_t dword, uint32_t st, int byte)
+{
+    if (!C) return kmp_delta(dword, st, byte);
+    const uint32_t c = (dword >> (8 * byte)) & 0xFFu;
+    const uint32_t addr = (st << 6) | (c ^ st);
+    return *(const lds_u8_t*)(size_t)addr;
+}
+
 // sixteen transitions, nothing else (Z absorbs)
+template <bool C>
 __device__ __forceinline__ void kmp_chunk_fast(const uint4& v, uint32_t& st)
 {
     const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int q = 0; q < 16; ++q) st = kmp_delta(d[q >> 2], st, q & 3);
+    for (int q = 0; q < 16; ++q) st = kmp_step<C>(d[q >> 2], st, q & 3);
 }
 
 // Sixteen transitions, four at a time where the whole WAVE is in LOW states.  Four bytes x on from state s the
@@ -73,7 +88,7 @@ __device__ __forceinline__ uint32_t kmp_fresh4(uint32_t x, const KmpPrefix4& pf)
 }
 
 // EXT = false: the form for the whole wave in state 0 (thr is 0: registers only); EXT = true: in the states 0..K
-template <bool EXT>
+template <bool EXT, bool C>
 __device__ __forceinline__ void kmp_chunk_skip4(const uint4& v, uint32_t& st, bool& low, const KmpPrefix4& pf, uint32_t qbase,
                                                 uint32_t thr, uint32_t& nfast)
 {
@@ -93,7 +108,7 @@ __device__ __forceinline__ void kmp_chunk_skip4(const uint4& v, uint32_t& st, bo
             low = __ballot(st > thr) == 0;
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) st = kmp_delta(d[k], st, q);
+            for (int q = 0; q < 4; ++q) st = kmp_step<C>(d[k], st, q);
             low = EXT ? kmp_all_low(st, thr) : __ballot(st != 0u) == 0;
         }
     }
@@ -116,14 +131,14 @@ __device__ __forceinline__ void kmp_chunk_four(const uint4& v, uint32_t& r, uint
 }
 
 // sixteen transitions, counting (MASK: collecting) the entries into Z; CHECK: only bytes j0 <= j < jend
-template <bool CHECK, bool MASK>
+template <bool CHECK, bool MASK, bool C>
 __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base, uint32_t j0, uint32_t jend,
                                                 uint32_t& st, uint32_t& hits, uint32_t idw)
 {
     const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const uint32_t nx = kmp_delta(d[q >> 2], st, q & 3);
+        const uint32_t nx = kmp_step<C>(d[q >> 2], st, q & 3);
         const uint32_t real = nx < idw ? nx : idw;  // Z -> the accept state's own row
         if (CHECK) {
             const uint32_t j = j_base + q;
@@ -153,20 +168,31 @@ __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base,
 // four bytes on from state s: (id | 2), with the absorbing Z | 2 = 4w + 3 if an occurrence ended on the way.  The
 // workgroup computes these rows itself before it starts, four lookups in the byte table per entry (0.5 us), so the
 // codes are the text's own and the plan carries nothing for them.
-template <bool PREFIX, bool FOUR>  // PREFIX: the automaton of the 62-byte prefix (m > 254; FOUR: m > 62); hits are verified
-__global__ __launch_bounds__((FOUR ? kKmpFourWaves : kRunWaves) * 64) void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns,
-                                                           uint32_t dfa_off, const BatchItem* __restrict__ batch)
+// COMPACT (round 4) — FIVE four-wave workgroups per CU instead of one of sixteen waves.  The PMC passes of round 3 say
+// the kernel waits (SQ_WAIT_ANY 65 % of the wave cycles; VALU, scalar unit and LDS each under a third busy): every wave
+// has ONE line of its 64 runs in flight and one chain of dependent lookups, so what it needs is more waves, and the 94
+// VGPRs of this kernel allow five per SIMD where a 1024-thread workgroup next to a spread table (33 KB at m = 32, 64 KB
+// from 63 states on) allowed four.  So: the table COMPACT (kmp_step<true>: (w + 2) * 256 bytes, 16 KB at the most), the
+// automaton that of the pattern or of its 60-byte prefix (kKmpCompactWindow — five times table + Q + four slabs must fit
+// the CU's 160 KB of LDS), 256-thread workgroups — one wave per SIMD each, so any five co-reside.  The accept row's id
+// must be a multiple of 4 like every other (row id * 64): Z = 4 (w + 1), and the counting walk's |next - min(next, 4w)|
+// counts an occurrence as 4 (undone once, at the end).
+template <bool PREFIX, bool FOUR, bool COMPACT = false>  // PREFIX: the automaton of a prefix (62 bytes; COMPACT: 60); hits are verified
+__global__ __launch_bounds__((COMPACT ? kKmpCompactWaves : FOUR ? kKmpFourWaves : kRunWaves) * 64, COMPACT ? kKmpCompactPerCu : FOUR ? 3 : 4)
+void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns, uint32_t dfa_off, const BatchItem* __restrict__ batch)
 {
+    static_assert(!(FOUR && COMPACT), "the four-byte table lives in the gaps of the spread table");
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
-    constexpr int kW = FOUR ? kKmpFourWaves : kRunWaves;  // waves of the workgroup
+    constexpr int kW = COMPACT ? kKmpCompactWaves : FOUR ? kKmpFourWaves : kRunWaves;  // waves of the workgroup
+    constexpr bool C = COMPACT;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t w = PREFIX ? kKmpPrefix : m;  // length the automaton recognises
-    const uint32_t idw = w < 63 ? 4 * w : 254u, Z = idw + 1;
+    const uint32_t w = PREFIX ? (COMPACT ? kKmpCompactWindow : kKmpPrefix) : m;  // length the automaton recognises
+    const uint32_t idw = (COMPACT || w < 63) ? 4 * w : 254u, Z = COMPACT ? idw + 4 : idw + 1;
     constexpr bool four = FOUR;
     // (+ two rows of that table: 4w + 2, the accept state's, and 4w + 3 = Z | 2, all Z: a lane that fell into Z stays there)
-    const uint32_t table_bytes = (Z + 1 + (four ? 2u : 0u)) * 256;
+    const uint32_t table_bytes = COMPACT ? (w + 2) * 256 : (Z + 1 + (four ? 2u : 0u)) * 256;
     KmpPrefix4 pf;
     {
         const uint32_t p = *reinterpret_cast<const uint32_t*>(a.blob);  // P[0..4) (the pattern slot is zero-padded)
@@ -176,7 +202,7 @@ __global__ __launch_bounds__((FOUR ? kKmpFourWaves : kRunWaves) * 64) void kmp_r
         pf.p1 = p << 24;
     }
     const uint32_t qbase = table_bytes;  // Q[s] = P[s..s+4) for the states kmp_chunk_skip4 covers (256 bytes)
-    const uint32_t stored = (w < 63 ? w + 1 : 256u) * 256u;  // the blob's rows (tables.cpp kmp_runs_tables)
+    const uint32_t stored = ((COMPACT || w < 63) ? w + 1 : 256u) * 256u;  // the blob's rows (tables.cpp kmp_runs_tables)
     const uint32_t thr = *reinterpret_cast<const uint32_t*>(a.blob + dfa_off + stored + 256);
     // FOUR: the text's two-bit codes, from the first words of the text's own allocation (TextCodes, kernels.hpp)
     const uint32_t shift4 = FOUR ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[0] : 0u;
@@ -186,7 +212,13 @@ __global__ __launch_bounds__((FOUR ? kKmpFourWaves : kRunWaves) * 64) void kmp_r
     {
         const uint4* g = reinterpret_cast<const uint4*>(a.blob + dfa_off);
         uint4* t = reinterpret_cast<uint4*>(smem);
-        if (w < 63) {
+        if (COMPACT) {
+            // the blob's rows as they are, row Z behind them, then Q
+            for (uint32_t i = threadIdx.x; i < (w + 1) * 16; i += kW * 64) t[i] = g[i];
+            const uint32_t z4 = Z * 0x01010101u;
+            if (threadIdx.x < 16) t[(w + 1) * 16 + threadIdx.x] = make_uint4(z4, z4, z4, z4);
+            else if (threadIdx.x < 32) t[table_bytes / 16 + threadIdx.x - 16] = g[stored / 16 + threadIdx.x - 16];
+        } else if (w < 63) {
             // the blob holds the rows of the states 0..w one after the other: row s goes to row 4s (the rows between
             // are never addressed), row Z is filled here, Q follows the table
             for (uint32_t i = threadIdx.x; i < (w + 1) * 16; i += kW * 64) t[(i >> 4) * 64 + (i & 15u)] = g[i];
@@ -250,8 +282,10 @@ __global__ __launch_bounds__((FOUR ? kKmpFourWaves : kRunWaves) * 64) void kmp_r
         const uint32_t mode0 = four ? 5u : w < 5 ? 0u : !PREFIX ? 1u : thr >= 16u ? 2u : 0u;
         uint32_t mode = mode0;
         bool dense = false;   // wave-uniform: many lanes saw an occurrence end in the last whole half
-        bool parked = false;  // PREFIX: first unverified prefix hit of this step
-        const uint8_t* parked_at = a.text;
+        // PREFIX: the first unverified prefix hit of this step, as the offset of its rest (text + start + w) in the lane's
+        // run; 0: none (a rest starts at least w bytes into the run).  One register, not a flag and a pointer: the compact
+        // instantiation has 96 to live in.
+        uint32_t parked_off = 0;
         auto half = [&](const uint32_t jb) {
             // one 16-byte chunk, counting; returns whether an occurrence ended in it
             // A chunk outside [j0, jend) — the text's last run ends early, the lanes of the last group may have no run
@@ -264,24 +298,20 @@ __global__ __launch_bounds__((FOUR ? kKmpFourWaves : kRunWaves) * 64) void kmp_r
                 const uint4 v = *reinterpret_cast<const uint4*>(io.rd + ((16u * q) ^ io.rswz));
                 if (!PREFIX) {
                     const uint32_t h0 = hits;
-                    if (whole) kmp_chunk_count<false, false>(v, j, j0, jend, st, hits, idw);
-                    else kmp_chunk_count<true, false>(v, j, j0, jend, st, hits, idw);
+                    if (whole) kmp_chunk_count<false, false, C>(v, j, j0, jend, st, hits, idw);
+                    else kmp_chunk_count<true, false, C>(v, j, j0, jend, st, hits, idw);
                     return hits != h0;
                 } else {
                     uint32_t hm = 0;
-                    if (whole) kmp_chunk_count<false, true>(v, j, j0, jend, st, hm, idw);
-                    else kmp_chunk_count<true, true>(v, j, j0, jend, st, hm, idw);
+                    if (whole) kmp_chunk_count<false, true, C>(v, j, j0, jend, st, hm, idw);
+                    else kmp_chunk_count<true, true, C>(v, j, j0, jend, st, hm, idw);
                     const bool seen = hm != 0;
                     while (hm) {  // the prefix ends at byte j+b: verify P[w..m)
                         const uint32_t b = __builtin_ctz(hm);
                         hm &= hm - 1;
-                        const uint8_t* rest = a.text + seg + j + b + 1;  // = text + start + w
-                        if (!parked) {
-                            parked = true;
-                            parked_at = rest;
-                        } else {
-                            hits += global_equal(rest, a.blob + w, m - w);
-                        }
+                        const uint32_t off = j + b + 1;  // text + seg + off = text + start + w
+                        if (parked_off == 0) parked_off = off;
+                        else hits += global_equal(a.text + seg + off, a.blob + w, m - w);
                     }
                     return seen;
                 }
@@ -289,14 +319,17 @@ __global__ __launch_bounds__((FOUR ? kKmpFourWaves : kRunWaves) * 64) void kmp_r
             if (jb >= j0 && jb + 64u <= jend) {  // the whole half is inside the run
                 bool seen = false;
                 if (!dense) {
-                    uint32_t at[4];  // state before each 16-byte chunk
+                    // state before each 16-byte chunk.  The compact prefix automaton keeps only the half's first (a hit of a
+                    // 60-byte prefix is rare, its half is walked again from the start): three registers of the 96 it has.
+                    constexpr bool kOneSave = PREFIX && COMPACT;
+                    uint32_t at[4];
                     if (mode == 1) {
                         bool low = __ballot(st != 0u) == 0;
                         uint32_t nfast = 0;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             at[q] = st;
-                            kmp_chunk_skip4<false>(run_piece(io, q), st, low, pf, qbase, 0u, nfast);
+                            kmp_chunk_skip4<false, C>(run_piece(io, q), st, low, pf, qbase, 0u, nfast);
                         }
                         if (nfast < 6) mode = thr >= 16u ? 2u : 0u;
                     } else if (FOUR && mode == 5) {
@@ -313,22 +346,22 @@ __global__ __launch_bounds__((FOUR ? kKmpFourWaves : kRunWaves) * 64) void kmp_r
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             at[q] = st;
-                            kmp_chunk_skip4<true>(run_piece(io, q), st, low, pf, qbase, thr, nfast);
+                            kmp_chunk_skip4<true, C>(run_piece(io, q), st, low, pf, qbase, thr, nfast);
                         }
                         if (nfast < 6) mode = 0u;
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             at[q] = st;
-                            kmp_chunk_fast(run_piece(io, q), st);
+                            kmp_chunk_fast<C>(run_piece(io, q), st);
                         }
                     }
                     seen = st == Z;
                     if (__any(seen)) {
                         if (seen) {
                             // the chunk in which the lane fell into Z: walk on from there, counting
-                            const uint32_t q0 = at[1] == Z ? 0u : at[2] == Z ? 1u : at[3] == Z ? 2u : 3u;
-                            st = q0 == 0 ? at[0] : q0 == 1 ? at[1] : q0 == 2 ? at[2] : at[3];
+                            const uint32_t q0 = kOneSave ? 0u : at[1] == Z ? 0u : at[2] == Z ? 1u : at[3] == Z ? 2u : 3u;
+                            st = (kOneSave || q0 == 0) ? at[0] : q0 == 1 ? at[1] : q0 == 2 ? at[2] : at[3];
 #pragma unroll 1
                             for (uint32_t q = q0; q < 4; ++q) careful(q, true);
                         }
@@ -348,9 +381,9 @@ __global__ __launch_bounds__((FOUR ? kKmpFourWaves : kRunWaves) * 64) void kmp_r
                     careful(q, j >= j0 && j + 16 <= jend);
                 }
             }
-            if (PREFIX && __any(parked)) {  // wave-uniform point: at most one parked hit per lane
-                hits += wave_verify(parked, parked_at, a.blob + w, m - w);
-                parked = false;
+            if (PREFIX && __any(parked_off != 0)) {  // wave-uniform point: at most one parked hit per lane
+                hits += wave_verify(parked_off != 0, a.text + seg + parked_off, a.blob + w, m - w);
+                parked_off = 0;
             }
         };
         for (uint32_t k = 0; k < nlines; ++k) {
@@ -363,6 +396,7 @@ __global__ __launch_bounds__((FOUR ? kKmpFourWaves : kRunWaves) * 64) void kmp_r
             half(k * kRunLine + 64u);
         }
     }
+    if (COMPACT && !PREFIX) hits >>= 2;  // the counting walk's |next - min(next, 4w)| is 4 per occurrence with Z = 4w + 4
     flush_hits(hits, a.count, smem);
 }
 
@@ -372,10 +406,37 @@ __global__ __launch_bounds__((FOUR ? kKmpFourWaves : kRunWaves) * 64) void kmp_r
 hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream, TextCodes codes)
 {
     const uint32_t m = a.m;
-    const uint32_t dfa_off = kTableOff + r16(2 * (m + 1));  // the transition table of kmp_runs (api.cpp build_blob)
-    // four text bytes per table step: the text holds at most four byte values and the plan's window is short enough for
-    // the table (a pattern over at most four symbols — any other cannot occur in such a text); tune(3,5): never (A/B)
+    // four text bytes per table step: the text holds at most four byte values and the plan carries the spread table of a
+    // window short enough for it (a.prefer_packed: a pattern over at most four symbols — any other cannot occur in
+    // such a text); tune(3,5): never (A/B)
     const bool four = a.prefer_packed != 0 && codes.shift < 7 && g_tune[3] != 5;
+#ifdef SMARTGPU_AB
+    const bool spread = four || g_tune[3] == 6;  // tune(3,6): round 3's one-workgroup-per-CU form on the spread table (A/B)
+#else
+    const bool spread = four;
+#endif
+    uint64_t lmin = g_tune[5] ? std::min<uint64_t>((uint64_t)g_tune[5], kRunLenMax / 2) : 2048;
+    if (!spread) {
+        // Every other text: the compact table, five four-wave workgroups per CU.
+        const uint32_t w = kmp_compact_window(m);  // bytes the automaton recognises; a run re-scans w-1
+        const size_t lds = (size_t)(w + 2) * 256 + kKmpQBytes + kKmpCompactWaves * (size_t)kLineSlab;
+        if (lmin < 8ull * (w - 1)) lmin = 8ull * (w - 1);
+        const uint64_t lfloor = 2ull * (w - 1) > 128 ? 2ull * (w - 1) : 128;  // small texts: see balanced_run_len
+        const int per_cu = g_tune[4] ? g_tune[4] : kKmpCompactPerCu;           // tune(4, .): workgroups per CU (A/B)
+        const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * per_cu * kKmpCompactWaves, lmin, 2 * lmin, lfloor);
+        const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
+        if (tr.count == 0) return hipSuccess;
+        const uint64_t grid = runs_grid(tr.count, num_cus, kKmpCompactWaves, per_cu);
+        trace_runs("kmp_runs (compact)", a, L, tr, grid);
+        if (m > w)
+            hipLaunchKernelGGL((kmp_runs<true, false, true>), dim3((uint32_t)grid, g_batch.count), dim3(64 * kKmpCompactWaves), lds, stream, a,
+                               (uint32_t)L, (uint64_t)tr.count, kmp_compact_off(m), g_batch.items);
+        else
+            hipLaunchKernelGGL((kmp_runs<false, false, true>), dim3((uint32_t)grid, g_batch.count), dim3(64 * kKmpCompactWaves), lds, stream, a,
+                               (uint32_t)L, (uint64_t)tr.count, kmp_compact_off(m), g_batch.items);
+        return hipGetLastError();
+    }
+    const uint32_t dfa_off = kmp_spread_off(m);  // the spread table (api.cpp build_blob)
     const uint32_t w = a.prefer_packed ? a.prefer_packed : kmp_window(m);  // bytes the automaton recognises (with that table: api.cpp); a run re-scans w-1
     const uint32_t rows = (w < 63 ? 4 * w + 2 : 256) + (four ? 2 : 0);  // up to the absorbing row Z (+ rows 4w+2, 4w+3 of the four-byte table)
     const size_t table = (size_t)rows * 256;
@@ -384,7 +445,6 @@ hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream, T
     const size_t lds = table + kKmpQBytes + waves * (size_t)kLineSlab;
     // runs of 2-4 KiB: at least 8x the w-1 bytes a run re-scans, at most 8 KiB (the loader's
     // over-read past the last run stays inside the text's back pad)
-    uint64_t lmin = g_tune[5] ? std::min<uint64_t>((uint64_t)g_tune[5], kRunLenMax / 2) : 2048;
     if (lmin < 8ull * (w - 1)) lmin = 8ull * (w - 1);
     const uint64_t lfloor = 2ull * (w - 1) > 128 ? 2ull * (w - 1) : 128;  // small texts: see balanced_run_len
     const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * waves, lmin, 2 * lmin, lfloor);
@@ -392,7 +452,6 @@ hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream, T
     if (tr.count == 0) return hipSuccess;
     const uint64_t grid = runs_grid(tr.count, num_cus, waves);
     trace_runs("kmp_runs", a, L, tr, grid);
-    // tune(3,5): without the four-byte table — round 2's kernel on the same tables (A/B)
 #define SG_KMP_RUNS4(P_, F_)                                                                             \
     do {                                                                                                 \
         if (lds > 64 * 1024) allow_lds(reinterpret_cast<const void*>(kmp_runs<P_, F_>), lds);            \
@@ -402,13 +461,15 @@ hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream, T
     if (four) {
         if (m > w) SG_KMP_RUNS4(true, true);  // beyond 62 bytes: the prefix's automaton
         else SG_KMP_RUNS4(false, true);
-    } else {
+    }
+#ifdef SMARTGPU_AB
+    else {
         if (m > w) SG_KMP_RUNS4(true, false);  // beyond 254 bytes (62 with the four-byte table's window)
         else SG_KMP_RUNS4(false, false);
     }
+#endif
 #undef SG_KMP_RUNS4
     return hipGetLastError();
 }
-
 
 }  // namespace sg

@@ -27,6 +27,10 @@ constexpr uint32_t kKmpWindow = 254;   // KMP (kmp_runs): states 0..w plus the a
 // 0.188-0.212 (62) on rand128, the same order on English and rand2.  62 keeps the ids 4s (tables.cpp).
 constexpr uint32_t kKmpPrefix = 62;
 constexpr uint32_t kmp_window(uint32_t m) { return m <= kKmpWindow ? m : kKmpPrefix; }
+// kmp_runs<., false, COMPACT>: the automaton of the pattern or of its 60-byte prefix in a compact table — five four-wave
+// workgroups per CU, each with its own copy (launch_common.hpp, k_kmp.hip)
+constexpr uint32_t kKmpCompactWindow = 60;
+constexpr uint32_t kmp_compact_window(uint32_t m) { return m < kKmpCompactWindow ? m : kKmpCompactWindow; }
 constexpr uint32_t kKmpQBytes = 272;   // kmp_runs: after the transitions, Q[s] = P[s..s+4) for 64 states (LDS), thr = 4K, 12 bytes of padding
 constexpr uint32_t kKmpDfaMaxM = 255;  // KMP: the automaton's states are u8, so its (w+1)*256-byte transition
                                        // table (<= 64 KB of LDS) recognises w = min(m, 255) bytes; longer
@@ -75,6 +79,10 @@ struct BatchItem {
 //  BNDM: u32 B[256]
 //  EPSM: u32 fp[4], u32 fpmask[4]   (first min(m,16) pattern bytes as dwords + byte masks)
 constexpr uint32_t kTableOff = kPatternBytes;
+// KMP: i16 next[m+1], then (16-byte aligned) the compact table of kmp_compact_window(m) — (w + 1) rows + Q —, then, where the
+// plan carries one (a pattern over at most four symbols: the four-byte form; the A/B build: always), the spread table
+constexpr uint32_t kmp_compact_off(uint32_t m) { return kTableOff + ((2 * (m + 1) + 15u) & ~15u); }
+constexpr uint32_t kmp_spread_off(uint32_t m) { return kmp_compact_off(m) + (kmp_compact_window(m) + 1) * 256 + kKmpQBytes; }
 constexpr uint32_t kBndmlWindow = 64;           // bytes of the pattern bndml_scan keeps in its bit vectors (multiple of 32, <= 256)
 
 struct LaunchInfo {

@@ -49,7 +49,7 @@ bool tune_supported(int key, int value)
 #else
     switch (key) {
         case 0: return value == 0 || value == 1 || value == 3;  // 2: Horspool on the bank-private tiles
-        case 3: return value == 0 || value == 5;                 // superseded KMP kernels (5: kmp_runs without its four-byte table)
+        case 3: return value == 0 || value == 5;                 // superseded KMP kernels (5: kmp_runs without its four-byte table; 6: round 3's one-workgroup form)
         case 6: return value == 0 || value == 5;                 // superseded SO kernels (5: so_runs without the four-symbol table)
         case 7: return value == 0;                               // packed load policies
         default: return true;

@@ -126,14 +126,14 @@ bool four_symbol_codes(const uint32_t set[8], uint32_t* shift, uint32_t* symtab)
     return false;
 }
 
-void kmp_runs_tables(const uint8_t* P, uint32_t w, std::vector<uint8_t>& out)
+void kmp_runs_tables(const uint8_t* P, uint32_t w, std::vector<uint8_t>& out, bool compact)
 {
     // ids: fewer than 63 states: id(s) = 4s, Z = 4w + 1, the table ends there.  Otherwise id(s) = rotl8(s, 2) — the
     // low states a lane is usually in then differ in the bits that select the LDS bank —, id(w) = 254, Z = 255;
     // rotl8 maps only s = 191 to 254 and only s = 255 to 255, so state 191 (if there is one besides w) takes the
     // slot w gave up.  Z = id(w) + 1 is the largest id (the kernel's min(next, id(w)) turns Z back into w).
     const bool small = w < 63;
-    const uint32_t idw = small ? 4 * w : 254u, Z = idw + 1;
+    const uint32_t idw = small ? 4 * w : 254u, Z = (compact && small) ? idw + 4 : idw + 1;
     uint8_t id[256];
     for (uint32_t st = 0; st <= w; ++st) id[st] = static_cast<uint8_t>(small ? 4 * st : ((st << 2) | (st >> 6)) & 255u);
     if (!small && w > 191) id[191] = id[w];

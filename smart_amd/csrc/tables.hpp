@@ -32,13 +32,15 @@ std::vector<uint8_t> kmp_dfa(const uint8_t* P, uint32_t m);
 // (0 = "c does not occur in P": every state goes to 0), table[s*k1 + col], k1 columns.
 // Returns colmap (256 bytes) followed by the table; *k1 = row stride.
 std::vector<uint8_t> kmp_dfa_compressed(const uint8_t* P, uint32_t m, uint32_t* k1);
-// kmp_runs' tables for the automaton of P[0..w), w <= 254, appended to `out` (layout: DESIGN.md §4, kernels.hip
+// kmp_runs' tables for the automaton of P[0..w), w <= 254, appended to `out` (layout: DESIGN.md §4, k_kmp.hip
 // kmp_runs): the transitions — row id(s) XOR-swizzled by its id, every transition into the accept state leading to
 // the absorbing row Z; kmp_runs_table_bytes(w) bytes: the w+1 rows of the states one after the other while their ids
 // are 4s (w < 63; the kernel spreads them over (Z+1)*256 bytes of LDS and fills row Z), else all 256 rows —, then
 // 272 bytes: Q[s] = P[s..s+4) for the states 0..K that have no border (64 dwords), thr = 4K, 12 bytes of padding.
 // Built row by row from the border's row like kmp_dfa, in place.
-void kmp_runs_tables(const uint8_t* P, uint32_t w, std::vector<uint8_t>& out);
+// compact (w <= 62; kmp_runs<., false, COMPACT>, which keeps the rows as stored: row s at s * 256): the absorbing row's
+// id is a multiple of 4 like every other, Z = 4 (w + 1) — the only difference, in the entries that lead INTO it.
+void kmp_runs_tables(const uint8_t* P, uint32_t w, std::vector<uint8_t>& out, bool compact = false);
 uint32_t kmp_runs_table_bytes(uint32_t w);
 // Two-bit codes for a set of at most four byte values (bit c of the 256-bit set <=> value c is a member): the lowest
 // shift < 7 such that (c >> shift) & 3 tells the members apart, and symtab = the member of each code in byte `code`

@@ -78,6 +78,7 @@ def _load(path):
         "smartgpu_text_alphabet": (i32, [vp, vp]),
         "smartgpu_search64": (i32, [i32, vp, u32, vp, u64, u64, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "smartgpu_search_batch64": (i32, [i32, vp, u32, u32, vp, u64, u64, vp, vp, vp, C.POINTER(C.c_double)]),
+        "smartgpu_search_batch64_each": (i32, [i32, vp, u32, u32, vp, u64, u64, vp, vp, vp, C.POINTER(C.c_double)]),
         "smartgpu_msearch_batch64": (i32, [i32, vp, u32, u32, vp, i32, vp, vp, C.POINTER(C.c_double)]),
         "smartgpu_find64": (i32, [vp, u32, vp, u64, u64, vp, u64, C.POINTER(u64)]),
         "smartgpu_last_times": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -100,6 +101,8 @@ def _load(path):
         "smartgpu_mtext_free": (None, [vp]),
         "smartgpu_mtext_length": (u64, [vp]),
         "smartgpu_mtext_ngpus": (i32, [vp]),
+        "smartgpu_mtext_partition": (i32, [u64, i32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]),
+        "smartgpu_selftest_launch_pool": (i32, [i32, i32]),
         "smartgpu_msearch64": (i32, [i32, vp, u32, vp, i32, C.POINTER(u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "smartgpu_probe_read_ms": (i32, [vp, i32, C.POINTER(C.c_double)]),
     }
@@ -320,6 +323,15 @@ class MultiText:
             pass
 
 
+def mtext_partition(n, ngpus, g):
+    """(begin, own, held) of shard g of a text of n bytes over ngpus devices — smartgpu_mtext_partition, the arithmetic
+    smartgpu_mtext_upload / _generate shard with; no device needed."""
+    b, o, h = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    if lib().smartgpu_mtext_partition(n, ngpus, g, C.byref(b), C.byref(o), C.byref(h)) != 0:
+        raise _err("mtext_partition")
+    return int(b.value), int(o.value), int(h.value)
+
+
 def search(algo, P, text, off=0, n=None):
     """(count, pre_ms, run_ms) of `algo` for P in text[off..off+n)."""
     P = _u8(P)
@@ -345,10 +357,10 @@ def _pattern_set(patterns):
     return pats, ptrs, m
 
 
-def search_batch(algo, patterns, text, off=0, n=None, per_pattern_times=True):
+def search_batch(algo, patterns, text, off=0, n=None, per_pattern_times=True, each=False):
     """(counts, pre_ms, run_ms, batch_ms) of `algo` for a whole pattern set over text[off..off+n): the
     harness loop of smart.c:312-345 as one call (smartgpu_search_batch64).  run_ms is None without
-    per_pattern_times."""
+    per_pattern_times.  each: every pattern its own launch and event pair (smartgpu_search_batch64_each)."""
     pats, ptrs, m = _pattern_set(patterns)
     K = len(pats)
     if n is None:
@@ -357,8 +369,9 @@ def search_batch(algo, patterns, text, off=0, n=None, per_pattern_times=True):
     pre = np.zeros(K, dtype=np.float64)
     run = np.zeros(K, dtype=np.float64) if per_pattern_times else None
     batch = C.c_double(0.0)
-    rc = lib().smartgpu_search_batch64(algo_id(algo), C.cast(ptrs, C.c_void_p), m, K, text._h, off, n, counts.ctypes.data,
-                                       pre.ctypes.data, run.ctypes.data if run is not None else None, C.byref(batch))
+    fn = lib().smartgpu_search_batch64_each if each else lib().smartgpu_search_batch64
+    rc = fn(algo_id(algo), C.cast(ptrs, C.c_void_p), m, K, text._h, off, n, counts.ctypes.data,
+            pre.ctypes.data, run.ctypes.data if run is not None else None, C.byref(batch))
     if rc != 0:
         raise _err("search_batch64(%s) rc=%d" % (algo, rc))
     return counts, pre, run, float(batch.value)
@@ -430,8 +443,8 @@ def kernel_for(algo, P):
 def build_table(which, P):
     P = _u8(P)
     names = {"bad_char": 0, "good_suffix": 1, "kmp_next": 2, "shift_or": 3, "bndm": 4, "kmp_dfa": 5,
-             "kmp_dfa_compressed": 6, "shift_and": 7, "quick_search": 8, "kmp_runs": 9, "four_codes": 10, "hash3": 13, "hash5": 15, "hash8": 18}
-    out = np.empty(max(257, len(P) + 1, (len(P) + 1) * 256 + 257 if which.startswith("kmp_dfa") else 256 * 256 + 272 if which == "kmp_runs" else 0), dtype=np.int32)
+             "kmp_dfa_compressed": 6, "shift_and": 7, "quick_search": 8, "kmp_runs": 9, "four_codes": 10, "kmp_runs_compact": 11, "hash3": 13, "hash5": 15, "hash8": 18}
+    out = np.empty(max(257, len(P) + 1, (len(P) + 1) * 256 + 257 if which.startswith("kmp_dfa") else 256 * 256 + 272 if which.startswith("kmp_runs") else 0), dtype=np.int32)
     k = lib().smartgpu_build_table(names[which], P.ctypes.data, len(P), out.ctypes.data, len(out))
     if k < 0:
         raise _err("build_table")

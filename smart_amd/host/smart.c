@@ -61,7 +61,8 @@ struct options {
     int minlen, maxlen;
     const int *lengths;
     int occ, pre, dif, std, txt, tex, php;
-    int limit_ms;      /* -tb (smart.c:424: 300 ms) */
+    double limit_ms;   /* -tb (smart.c:424: 300 ms); fractions of a millisecond are accepted here (a search takes microseconds) */
+    int each;          /* -dif, -std or -tb given: every pattern is launched and timed on its own (smart.c:320-351) */
     int device;
     int gpus;          /* -gpus k: shard the text over k GPUs of this process, RCCL sum of the counts */
     long seed;         /* -seed S: srandom(S) instead of the reference's srand(time(NULL)) (smart.c:432): repeatable pattern sets */
@@ -85,12 +86,13 @@ static void usage(void)
     printf("\t-vshort       pattern lengths 1..16\n");
     printf("\t-occ          also print the mean number of occurrences\n");
     printf("\t-pre          report preprocessing and searching times separately\n");
-    printf("\t-tb L         give up on an algorithm when one search exceeds L ms (default 300)\n");
+    printf("\t-tb L         give up on an algorithm when one search exceeds L ms (default 300; 0.25 is a valid L)\n");
     printf("\t-dif          also print the best and the worst time\n");
     printf("\t-std          also print the standard deviation\n");
-    printf("\t              (a pattern set is searched in calls of up to %d patterns; on texts up to 32 MiB the\n", BATCH);
-    printf("\t              patterns of a call that share a kernel share ONE grid, so best, worst and std then\n");
-    printf("\t              describe the spread between such groups, not between single patterns)\n");
+    printf("\t              (a pattern set is searched in calls of up to %d patterns.  With -dif, -std or -tb every\n", BATCH);
+    printf("\t              pattern is launched and timed on its own, as the reference times every pattern; without\n");
+    printf("\t              them the patterns of a call that share a kernel share ONE grid on texts up to 32 MiB —\n");
+    printf("\t              faster, and only the mean is reported then)\n");
     printf("\t-txt          write the result table as results/<code>/<corpus>.txt\n");
     printf("\t-tex          write it as a LaTeX tabular too\n");
     printf("\t-php          write it as a PHP array (results/<code>/<corpus>.php) too\n");
@@ -131,6 +133,17 @@ static int is_number(const char *s)
     for (; *s; ++s)
         if (*s < '0' || *s > '9') return 0;
     return 1;
+}
+
+static int is_decimal(const char *s) /* digits with at most one '.' */
+{
+    int digits = 0, dots = 0;
+    for (; *s; ++s) {
+        if (*s == '.') ++dots;
+        else if (*s >= '0' && *s <= '9') ++digits;
+        else return 0;
+    }
+    return digits > 0 && dots <= 1;
 }
 
 static void upper(char *dst, const char *src)
@@ -274,9 +287,11 @@ static void run_corpus(const struct options *o, const char *corpus, const unsign
             }
             /* The reference's loop (smart.c:312-345) spawns one process per pattern; here the whole set goes
              * to the engine in calls of BATCH patterns (smartgpu_search_batch64: tables of the set in one
-             * arena, launches back to back, one read-back).  A pattern's time e is the wall time of its call
-             * divided by the patterns in it (+ its preprocessing unless -pre); best/worst/std are taken
-             * over the per-pattern device times (HIP events) scaled to that mean. */
+             * arena, launches back to back, one read-back).  A pattern's time e is its share — by device time,
+             * HIP events — of the wall time of its call (+ its preprocessing unless -pre).  With -dif, -std or -tb
+             * (o->each) every pattern has its own launch and event pair, so best, worst, std and the -tb bound mean
+             * what smart.c:337-351 means; without them patterns that share a kernel share one grid on texts up to
+             * 32 MiB and a group's time is divided evenly among its patterns (only the mean is printed then). */
             int done = 0;
             if (!mtext) {
                 /* an untimed pass first, the whole set over (at most) the first MiB: code object loads of every kernel
@@ -294,8 +309,8 @@ static void run_corpus(const struct options *o, const char *corpus, const unsign
                 double batch_ms = 0;
                 int rc = mtext ? smartgpu_msearch_batch64(algo, (const uint8_t *const *)(pats + done), (uint32_t)m, (uint32_t)kb, mtext,
                                                           o->reduce, bcount, bpre, &batch_ms)
-                               : smartgpu_search_batch64(algo, (const uint8_t *const *)(pats + done), (uint32_t)m, (uint32_t)kb, text, 0,
-                                                         (uint64_t)n, bcount, bpre, brun, &batch_ms);
+                               : (o->each ? smartgpu_search_batch64_each : smartgpu_search_batch64)(
+                                     algo, (const uint8_t *const *)(pats + done), (uint32_t)m, (uint32_t)kb, text, 0, (uint64_t)n, bcount, bpre, brun, &batch_ms);
                 double dev_sum = 0;
                 if (rc == SMARTGPU_OK && !mtext)
                     for (int k = 0; k < kb; ++k) dev_sum += brun[k];
@@ -687,7 +702,7 @@ int main(int argc, char **argv)
         if (!strcmp(a, "-h")) { usage(); return 0; }
         else if (!strcmp(a, "-pset")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.runs = atoi(argv[++i]); }
         else if (!strcmp(a, "-tsize")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.tsize = atol(argv[++i]) * 1048576L; }
-        else if (!strcmp(a, "-tb")) { if (!has1 || !is_number(argv[i + 1])) { printf("%s", bad); return 0; } o.limit_ms = atoi(argv[++i]); }
+        else if (!strcmp(a, "-tb")) { if (!has1 || !is_decimal(argv[i + 1])) { printf("%s", bad); return 0; } o.limit_ms = atof(argv[++i]); o.each = 1; }
         else if (!strcmp(a, "-text")) { if (!has1) { printf("%s", bad); return 0; } snprintf(o.text_arg, sizeof o.text_arg, "%s", argv[++i]); }
         else if (!strcmp(a, "-plen")) {
             if (!has2 || !is_number(argv[i + 1]) || !is_number(argv[i + 2])) { printf("%s", bad); return 0; }
@@ -706,8 +721,8 @@ int main(int argc, char **argv)
         }
         else if (!strcmp(a, "-occ")) o.occ = 1;
         else if (!strcmp(a, "-pre")) o.pre = 1;
-        else if (!strcmp(a, "-dif")) o.dif = 1;
-        else if (!strcmp(a, "-std")) o.std = 1;
+        else if (!strcmp(a, "-dif")) o.dif = o.each = 1;
+        else if (!strcmp(a, "-std")) o.std = o.each = 1;
         else if (!strcmp(a, "-txt")) o.txt = 1;
         else if (!strcmp(a, "-tex")) o.tex = 1;
         else if (!strcmp(a, "-php")) o.php = 1;

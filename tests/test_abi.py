@@ -215,6 +215,72 @@ def test_kmp_runs_tables_are_the_automaton_renumbered(oracle):
         assert q[64] == 4 * K and not q[65:].any() and not q[K + 1:64].any()
 
 
+def test_kmp_compact_tables_are_the_automaton_renumbered(oracle):
+    """The COMPACT tables of kmp_runs<., false, COMPACT> (round 4: five four-wave workgroups per CU, each with its own
+    table): the automaton of the pattern or of its 60-byte prefix, state s in row s (id 4s, the row XOR-swizzled by its
+    id), transitions into the accept state lead to the absorbing row Z = 4 (w + 1) that follows the states' rows."""
+    cases = [oracle.gen_text(177 + i, sigma, 0, m) for i, (sigma, m) in enumerate(
+        [(2, 1), (2, 5), (2, 9), (2, 40), (2, 59), (2, 60), (2, 61), (2, 200), (4, 17), (4, 100), (128, 1), (128, 2), (128, 4),
+         (128, 5), (128, 32), (128, 60), (128, 61), (128, 62), (128, 254), (128, 255), (128, 4096), (256, 33)])]
+    cases += [np.frombuffer(b"abcabcabcabd", np.uint8), np.frombuffer(b"aaaaaaaaab", np.uint8), np.tile(np.frombuffer(b"ab", np.uint8), 120)]
+    for P in cases:
+        w = min(len(P), 60)  # kernels.hpp kmp_compact_window
+        Pw = P[:w]
+        dfa = smart_amd.build_table("kmp_dfa", Pw).reshape(w + 1, 256)
+        got = smart_amd.build_table("kmp_runs_compact", P).astype(np.uint8)
+        Z = 4 * w + 4
+        assert Z <= 252 and len(got) == (w + 2) * 256 + 272, (len(P), len(got))
+        want = np.zeros((w + 2, 256), np.uint8)
+        for s in range(w + 1):
+            for c in range(256):
+                nx = int(dfa[s, c])
+                want[s, c ^ (4 * s)] = Z if nx == w else 4 * nx
+        want[w + 1, :] = Z
+        assert np.array_equal(got[:(w + 2) * 256].reshape(w + 2, 256), want), len(P)
+        # Q and thr are the spread tables' (same states, same ids)
+        if len(P) <= 60:
+            spread = smart_amd.build_table("kmp_runs", P).astype(np.uint8)
+            assert np.array_equal(got[(w + 2) * 256:], spread[-272:])
+
+
+def test_multi_gpu_partition_arithmetic_of_the_c_library():
+    """smartgpu_mtext_partition — what smartgpu_mtext_upload / _generate shard a text with (api.cpp shard_begin): for k up to
+    16 and lengths that are not multiples of k the shards' own ranges tile [0, n) exactly, differ by at most one byte, hold
+    SMARTGPU_XSIZE - 1 bytes of overlap (never beyond n) — and counting starts by ownership gives every start position of
+    every pattern length to exactly one shard."""
+    X = 4200
+    for n in (0, 1, 7, 8, 9, 1_000_003, (1 << 32) + 5, (1 << 35) - 1, (1 << 35) + 12345):
+        for k in (1, 2, 3, 5, 8, 16):
+            parts = [engine.mtext_partition(n, k, g) for g in range(k)]
+            assert parts[0][0] == 0 and sum(o for _, o, _ in parts) == n
+            for g, (b, o, h) in enumerate(parts):
+                assert b == sum(x[1] for x in parts[:g])                     # contiguous, in order
+                assert o in (n // k, n // k + 1)                            # balanced
+                assert h == min(n, b + o + X - 1) - b and b + h <= n        # own + overlap, inside the text
+            assert [o for _, o, _ in parts] == sorted((o for _, o, _ in parts), reverse=True)  # the longer shards first
+            # ownership by start position: shard g counts starts s in [b, b+o) with s + m <= n — smartgpu_msearch* searches
+            # span = min(held, own + m - 1) bytes of the shard, i.e. starts [b, b + span - m + 1)
+            for m in (1, 2, 4200):
+                owned = 0
+                for b, o, h in parts:
+                    span = min(h, o + m - 1)
+                    owned += max(0, span - m + 1)
+                assert owned == max(0, n - m + 1), (n, k, m)
+    with pytest.raises(smart_amd.SmartGpuError):
+        engine.mtext_partition(100, 8, 8)
+    with pytest.raises(smart_amd.SmartGpuError):
+        engine.mtext_partition(100, 17, 0)
+
+
+def test_launch_pool_of_the_multi_gpu_search():
+    """The host threads that enqueue the k devices' launches of smartgpu_msearch* at once (api.cpp LaunchPool), without
+    a device: every job of every round runs exactly once, with the number of jobs changing from round to round."""
+    L = engine.lib()
+    for k in (1, 2, 8, 16):
+        assert L.smartgpu_selftest_launch_pool(k, 200) == 0, L.smartgpu_last_error().decode()
+    assert L.smartgpu_selftest_launch_pool(0, 1) != 0 and L.smartgpu_selftest_launch_pool(17, 1) != 0
+
+
 def test_kernel_choice_follows_the_pattern(oracle):
     """The plan picks the kernel from the pattern's own symbols (api.cpp build_blob, DESIGN.md §4);
     smartgpu_kernel_for answers without a device."""

@@ -143,6 +143,12 @@ def test_plain_multi_gpu_invocation_launches_its_ranks():
     d = json.loads(line)
     assert d == {"check_launch": True, "n_gpus": 2, "rank_id_sum": 3, "launched_by": "torch.distributed.run",
                  "master_addr": "127.0.0.1"}
+    # the node's eight ranks (gloo, no GPU): the launcher starts all of them and they all meet
+    out8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--check-launch"],
+                          env=env, capture_output=True, text=True, timeout=600)
+    assert out8.returncode == 0, out8.stderr[-2000:]
+    d8 = json.loads([ln for ln in out8.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d8["n_gpus"] == 8 and d8["rank_id_sum"] == 36 and d8["master_addr"] == "127.0.0.1"
     # a rank count that does not match the launcher's world size is refused
     env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
@@ -168,5 +174,9 @@ def test_two_ranks_rehearsed_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["config"]["ranks"] == 2 and "gloo, rehearsal" in d["config"]["sharding"]
+    # the live group: gloo, two ranks — both on the one GPU of this box, and the record says so
+    assert d["rccl"]["world_size"] == 2 and d["rccl"]["backend"] == "gloo" and d["rccl"]["distinct_devices"] == 1
+    assert [r[0] for r in d["rccl"]["devices"]] == [0, 1]
+    assert abs(d["value_per_gpu"] * 2 - d["value"]) < 0.02 and d["aggregate"] == d["value"]
     assert d["config"]["text_bytes_per_gpu"] == (1 << 26) + 31  # rank 0's shard: its starts plus m-1 bytes of the next
     assert "all 5 counts equal" in d["counts_verified"] and d["roofline"]["bytes_per_launch"] == (1 << 26) + 31
