@@ -341,7 +341,7 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
             *halo = m - 1;  // forward halo: the automaton re-scans m-1 bytes
             blob.resize((blob.size() + 15) & ~size_t(15), 0);  // the transition table is 16-byte aligned
             // kmp_runs<., false, COMPACT> (round 4; every text that is not a four-symbol text): the automaton over
-            // kmp_compact_window(m) bytes — the pattern, or its 60-byte prefix — with an ABSORBING accept row Z (every transition
+            // kmp_compact_window(m) bytes — the pattern, or its 56-byte prefix — with an ABSORBING accept row Z (every transition
             // into the accept state w leads to Z, Z leads to Z; row id(w) holds the real delta(w, .)) and the table of the
             // four-bytes-at-a-time forms (tables.cpp), stored as the kernel keeps it: row s at s * 256.
             sg::kmp_runs_tables(P, sg::kmp_compact_window(m), blob, true);

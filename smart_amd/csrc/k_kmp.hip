@@ -173,11 +173,15 @@ __device__ __forceinline__ void kmp_chunk_count(const uint4& v, uint32_t j_base,
 // has ONE line of its 64 runs in flight and one chain of dependent lookups, so what it needs is more waves, and the 94
 // VGPRs of this kernel allow five per SIMD where a 1024-thread workgroup next to a spread table (33 KB at m = 32, 64 KB
 // from 63 states on) allowed four.  So: the table COMPACT (kmp_step<true>: (w + 2) * 256 bytes, 16 KB at the most), the
-// automaton that of the pattern or of its 60-byte prefix (kKmpCompactWindow — five times table + Q + four slabs must fit
+// automaton that of the pattern or of its 56-byte prefix (kKmpCompactWindow — five times table + Q + four slabs must fit
 // the CU's 160 KB of LDS), 256-thread workgroups — one wave per SIMD each, so any five co-reside.  The accept row's id
 // must be a multiple of 4 like every other (row id * 64): Z = 4 (w + 1), and the counting walk's |next - min(next, 4w)|
 // counts an occurrence as 4 (undone once, at the end).
-template <bool PREFIX, bool FOUR, bool COMPACT = false>  // PREFIX: the automaton of a prefix (62 bytes; COMPACT: 60); hits are verified
+// Measured against round 3's form (tune(3,6), A/B build, alternating, 1 GiB): m = 16: -6 % time on rand128, English and rand32;
+// m = 32 ... 56: -3 ... -7 %; longer patterns (the prefix automaton) and rand256: equal.  Waves are what it lives on: the same
+// kernel with four workgroups per CU +12 ... +16 %, and with 8 KB slabs — both halves of a line parked at once, the next line
+// requested a half earlier, three workgroups per CU — +30 % (profiles/r04/e_ab_kmp_deep_*.log); six per CU do not fit its 96 VGPRs.
+template <bool PREFIX, bool FOUR, bool COMPACT = false>  // PREFIX: the automaton of a prefix (62 bytes; COMPACT: 56); hits are verified
 __global__ __launch_bounds__((COMPACT ? kKmpCompactWaves : FOUR ? kKmpFourWaves : kRunWaves) * 64, COMPACT ? kKmpCompactPerCu : FOUR ? 3 : 4)
 void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns, uint32_t dfa_off, const BatchItem* __restrict__ batch)
 {
@@ -320,7 +324,7 @@ void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns, uint32_t dfa_off, c
                 bool seen = false;
                 if (!dense) {
                     // state before each 16-byte chunk.  The compact prefix automaton keeps only the half's first (a hit of a
-                    // 60-byte prefix is rare, its half is walked again from the start): three registers of the 96 it has.
+                    // 56-byte prefix is rare, its half is walked again from the start): three registers of the 96 it has.
                     constexpr bool kOneSave = PREFIX && COMPACT;
                     uint32_t at[4];
                     if (mode == 1) {
@@ -422,12 +426,21 @@ hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream, T
         const size_t lds = (size_t)(w + 2) * 256 + kKmpQBytes + kKmpCompactWaves * (size_t)kLineSlab;
         if (lmin < 8ull * (w - 1)) lmin = 8ull * (w - 1);
         const uint64_t lfloor = 2ull * (w - 1) > 128 ? 2ull * (w - 1) : 128;  // small texts: see balanced_run_len
-        const int per_cu = g_tune[4] ? g_tune[4] : kKmpCompactPerCu;           // tune(4, .): workgroups per CU (A/B)
+        // workgroups per CU: five, if the runtime agrees that five are resident at once (a grid of five per CU of which four
+        // fit runs a fifth of the text as a tail round: +25 %, measured with a 60-byte window); tune(4, .): A/B
+        auto resident = [&](const void* kernel) {
+            static std::map<std::pair<const void*, size_t>, int> known;
+            int& n = known[{kernel, lds}];
+            if (n == 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 64 * kKmpCompactWaves, lds) != hipSuccess) n = kKmpCompactPerCu;
+            return n < 1 ? 1 : n;
+        };
+        const void* const kern = m > w ? reinterpret_cast<const void*>(kmp_runs<true, false, true>) : reinterpret_cast<const void*>(kmp_runs<false, false, true>);
+        const int per_cu = g_tune[4] ? g_tune[4] : std::min(kKmpCompactPerCu, resident(kern));
         const uint64_t L = balanced_run_len(a.s_begin, a.s_end, 64, (uint64_t)num_cus * per_cu * kKmpCompactWaves, lmin, 2 * lmin, lfloor);
         const TileRange tr = tiles_for(a.s_begin, a.s_end, L);
         if (tr.count == 0) return hipSuccess;
         const uint64_t grid = runs_grid(tr.count, num_cus, kKmpCompactWaves, per_cu);
-        trace_runs("kmp_runs (compact)", a, L, tr, grid);
+        trace_runs(per_cu == kKmpCompactPerCu ? "kmp_runs (compact, 5 per CU)" : "kmp_runs (compact, FEWER than 5 per CU)", a, L, tr, grid);
         if (m > w)
             hipLaunchKernelGGL((kmp_runs<true, false, true>), dim3((uint32_t)grid, g_batch.count), dim3(64 * kKmpCompactWaves), lds, stream, a,
                                (uint32_t)L, (uint64_t)tr.count, kmp_compact_off(m), g_batch.items);

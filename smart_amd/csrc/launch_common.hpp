@@ -77,7 +77,7 @@ constexpr int kRunWaves = 16;            // one 1024-thread workgroup per CU sha
 // kernels lose with fewer (rand128: so_runs +5 %, kmp_runs +11 % at 12 waves), so_runs<., FOUR> is indifferent (-1 ... +2 %).
 constexpr int kKmpFourWaves = 12;
 // kmp_runs<., false, COMPACT> (k_kmp.hip): FIVE four-wave workgroups per CU — 20 waves where the 1024-thread form has 16 —
-// each with its own compact table of the pattern or its 60-byte prefix: 5 x ((60 + 2) x 256 + 272 + 4 x 4096) = 162,640 of the
+// each with its own compact table of the pattern or its 56-byte prefix: 5 x ((56 + 2) x 256 + 272 + 4 x 4096) = 157,520 of the
 // CU's 163,840 bytes of LDS.
 constexpr int kKmpCompactWaves = 4, kKmpCompactPerCu = 5;
 static_assert(kKmpCompactPerCu * ((kKmpCompactWindow + 2) * 256 + kKmpQBytes + kKmpCompactWaves * kLineSlab) <= 160 * 1024, "five compact workgroups per CU");

@@ -217,14 +217,14 @@ def test_kmp_runs_tables_are_the_automaton_renumbered(oracle):
 
 def test_kmp_compact_tables_are_the_automaton_renumbered(oracle):
     """The COMPACT tables of kmp_runs<., false, COMPACT> (round 4: five four-wave workgroups per CU, each with its own
-    table): the automaton of the pattern or of its 60-byte prefix, state s in row s (id 4s, the row XOR-swizzled by its
+    table): the automaton of the pattern or of its 56-byte prefix, state s in row s (id 4s, the row XOR-swizzled by its
     id), transitions into the accept state lead to the absorbing row Z = 4 (w + 1) that follows the states' rows."""
     cases = [oracle.gen_text(177 + i, sigma, 0, m) for i, (sigma, m) in enumerate(
-        [(2, 1), (2, 5), (2, 9), (2, 40), (2, 59), (2, 60), (2, 61), (2, 200), (4, 17), (4, 100), (128, 1), (128, 2), (128, 4),
-         (128, 5), (128, 32), (128, 60), (128, 61), (128, 62), (128, 254), (128, 255), (128, 4096), (256, 33)])]
+        [(2, 1), (2, 5), (2, 9), (2, 40), (2, 55), (2, 56), (2, 57), (2, 200), (4, 17), (4, 100), (128, 1), (128, 2), (128, 4),
+         (128, 5), (128, 32), (128, 56), (128, 57), (128, 62), (128, 254), (128, 255), (128, 4096), (256, 33)])]
     cases += [np.frombuffer(b"abcabcabcabd", np.uint8), np.frombuffer(b"aaaaaaaaab", np.uint8), np.tile(np.frombuffer(b"ab", np.uint8), 120)]
     for P in cases:
-        w = min(len(P), 60)  # kernels.hpp kmp_compact_window
+        w = min(len(P), 56)  # kernels.hpp kmp_compact_window
         Pw = P[:w]
         dfa = smart_amd.build_table("kmp_dfa", Pw).reshape(w + 1, 256)
         got = smart_amd.build_table("kmp_runs_compact", P).astype(np.uint8)
@@ -238,7 +238,7 @@ def test_kmp_compact_tables_are_the_automaton_renumbered(oracle):
         want[w + 1, :] = Z
         assert np.array_equal(got[:(w + 2) * 256].reshape(w + 2, 256), want), len(P)
         # Q and thr are the spread tables' (same states, same ids)
-        if len(P) <= 60:
+        if len(P) <= 56:
             spread = smart_amd.build_table("kmp_runs", P).astype(np.uint8)
             assert np.array_equal(got[(w + 2) * 256:], spread[-272:])
 
