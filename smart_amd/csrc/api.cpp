@@ -270,6 +270,7 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
     uint64_t pairs = 0;          // ordered pairs of equal symbols in P: pairs / (m (m-1)) estimates P(two symbols are equal)
     uint32_t distinct = 0;       // symbols that occur in P
     uint32_t bndm_q_wanted = 1;  // BNDM: the q its statistics ask for (the plan's q also has to divide the window)
+    uint32_t hor_q = 0;          // HOR: the q of its q-gram bad-character table (patterns over two to four symbols), 0: the byte table
     {
         uint32_t cnt[256] = {0};
         for (uint32_t i = 0; i < m; ++i) distinct += cnt[P[i]]++ == 0;
@@ -296,6 +297,22 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
             std::vector<uint16_t> tab(256);
             for (int c = 0; c < 256; ++c)
                 tab[c] = static_cast<uint16_t>(bc[c]) | (c == P[m - 1] ? 0x8000u : 0u);
+            // Horspool over a pattern of two to four symbols (binary texts, DNA): the last BYTE says next to nothing — the
+            // shift is the distance to its previous occurrence, a byte or two (hor_scan on rand2: 16 % of 8 TB/s at any m).
+            // The bad-character rule on the window's last q BYTES instead (Horspool on the super-alphabet of q-grams, the
+            // table indexed by their 8-bit hash sum T[e-k] 2^k — on a 0/1 text the q-gram itself — as Lecroq's hash3/5/8.c
+            // do it): the shift is back at m - q + 1 for a gram that does not occur in P.  q = 8 for two symbols, 5 or 8 for
+            // three and four; the kernel is hor_scan's HASHq instantiation, the table has Horspool's layout (zero entry =
+            // flag | shift after a candidate).  Measured on 1 GiB, own kernel: rand2 m = 32 / 64 / 256+: 54 / 68 / 70 %
+            // (byte table: 16 %), rand4 m = 16 / 32 / 64+: 60 / 73 / 74 % (45-50 %).  q travels in bits 8.. of the plan's halo.
+            if (algo == SMARTGPU_HOR && distinct >= 2 && distinct <= 4 && m >= 16) {
+                hor_q = distinct <= 2 ? 8u : m < 48 ? 5u : 8u;
+                int32_t after = 1;
+                const std::vector<int32_t> sh = sg::qgram_hash_shifts(P, m, hor_q, &after);
+                for (int c = 0; c < 256; ++c)
+                    tab[c] = sh[c] == 0 ? static_cast<uint16_t>(0x8000u | after) : static_cast<uint16_t>(sh[c]);
+                *halo |= hor_q << 8;
+            }
             append(tab.data(), 512);
             uint8_t tab8[256];  // plain u8 shifts for the bank-private kernel (m <= 255)
             for (int c = 0; c < 256; ++c) tab8[c] = static_cast<uint8_t>(bc[c] > 255 ? 255 : bc[c]);
@@ -518,6 +535,8 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
         // (hor_scan's flat form, VAR 9, for Horspool and Tuned BM: 68-70 % on English and rand32 from 8 bytes on)
         if (algo == SMARTGPU_BM || algo == SMARTGPU_HOR || algo == SMARTGPU_TUNEDBM)
             own_holds = m >= 8 && !(distinct <= 8 && 2 * distinct <= m);  // not: a few symbols, each several times
+        // ... unless Horspool has its q-gram table for them and a window long enough for its shifts (within 5-10 points of so_runs)
+        if (hor_q) own_holds = distinct <= 2 ? m >= 64 : m >= 32;
         if (algo == SMARTGPU_BNDM || (algo == SMARTGPU_BNDML && m <= 32)) own_holds = *halo == bndm_q_wanted && (*halo >= 8 ? m >= 32 : m >= 16);  // *halo: bndm_scan's q
         if (own_holds && m > sg::short_pattern_max_m(algo)) {
             to_so = false;
@@ -1085,10 +1104,12 @@ int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, u
     // (the key is what launch_scan derives kernel, template arguments and grid from: prefer_packed — for KMP the window
     // of its table —, the Shift-Or reroute, sparse, and for BNDM / BNDML the q of bndm_scan that travels as halo;
     // a mixed set ran every BNDM pattern with the first pattern's q)
+    // (... and for Horspool the q of its q-gram table, bits 8.. of halo)
     const bool halo_is_q = algo == SMARTGPU_BNDM || algo == SMARTGPU_BNDML;
     auto key = [&](uint32_t k) {
         const uint32_t pp = algo == SMARTGPU_KMP ? plans[k].prefer_packed : (plans[k].prefer_packed ? 1u : 0u);
-        return (static_cast<uint64_t>(pp) << 16) | ((halo_is_q ? plans[k].halo & 0xFFu : 0u) << 8) | (plans[k].so_off ? 2u : 0u) | (plans[k].sparse ? 1u : 0u);
+        const uint32_t variant = halo_is_q ? plans[k].halo & 0xFFu : algo == SMARTGPU_HOR ? (plans[k].halo >> 8) & 0xFFu : 0u;
+        return (static_cast<uint64_t>(pp) << 16) | (variant << 8) | (plans[k].so_off ? 2u : 0u) | (plans[k].sparse ? 1u : 0u);
     };
     std::vector<uint32_t> order(K);
     for (uint32_t k = 0; k < K; ++k) order[k] = k;

@@ -454,8 +454,11 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a1, uint64_t 
 // ---------------------------------------------------------------------------
 // launchers (the packed regime of short / repetitive patterns is chosen by the dispatcher, launch.hip)
 // ---------------------------------------------------------------------------
-hipError_t launch_hor(const ScanArgs& a, int num_cus, hipStream_t stream)
+hipError_t launch_hor(const ScanArgs& a, uint32_t q, int num_cus, hipStream_t stream)
 {
+    // Horspool's q-gram bad-character table (patterns over two to four symbols, api.cpp build_blob): hor_scan's HASHq loop
+    if (q == 5) return launch_hor_var(SMARTGPU_HASH5, a, num_cus, stream);
+    if (q == 8) return launch_hor_var(SMARTGPU_HASH8, a, num_cus, stream);
     const uint32_t m = a.m, H = a.halo;
     if (!a.sparse && m >= 2 && g_tune[2] != 3) {  // windows survive: the flat form, two-wave workgroups as bm_scan (tune(2,3): round 2's loop)
         const size_t flds = 512 + 32 + LaneTile<kBmHalo>::bytes(kBmBusyT);

@@ -149,7 +149,10 @@ ScanArgs prepare_scan_args(int algo, ScanArgs a)
         case SMARTGPU_SO: a.so_off = kTableOff; break;
         case SMARTGPU_SA: a.so_off = g_tune[6] == 3 ? kTableOff + 1024 : kTableOff; break;
         case SMARTGPU_KMP: break;
-        default: a.fp_off = kTableOff + 768; break;  // the Horspool family: after the u16 and u8 tables
+        default:  // the Horspool family: the fingerprint after the u16 and u8 tables; halo = H (at most 32), Horspool's q above it
+            a.fp_off = kTableOff + 768;
+            a.halo &= 0xFFu;
+            break;
     }
     return a;
 }
@@ -184,7 +187,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
 #ifdef SMARTGPU_AB
             if (regime == 2) return launch_hor_bp(a, num_cus, stream);
 #endif
-            return launch_hor(a, num_cus, stream);
+            return launch_hor(a, (a_in.halo >> 8) & 0xFFu, num_cus, stream);  // q: the plan's q-gram table (api.cpp), 0: the byte table
         }
         case SMARTGPU_KR:
             // Short patterns, like the skip algorithms': the packed matcher (72-77 %).  Only the low m bits

@@ -146,7 +146,7 @@ inline void allow_lds(const void* kernel, size_t lds)
 
 // ---- the families' launch entry points (each defined next to its kernels) ---------------------------------------
 // k_hor.hip — a.halo = H; the packed regime is decided by the dispatcher (launch.hip) before these are called
-hipError_t launch_hor(const ScanArgs& a, int num_cus, hipStream_t stream);                 // HOR, TUNEDBM: hor_scan<.., 0> / the flat form <.., 9>
+hipError_t launch_hor(const ScanArgs& a, uint32_t q, int num_cus, hipStream_t stream);     // HOR, TUNEDBM: hor_scan<.., 0> / the flat form <.., 9>; q: <.., q>, the q-gram table
 hipError_t launch_hor_var(int algo, const ScanArgs& a, int num_cus, hipStream_t stream);   // RAITA, QS, HASH3/5/8
 hipError_t launch_kr(const ScanArgs& a, int num_cus, hipStream_t stream);                  // Karp-Rabin on the bank-private tiles
 #ifdef SMARTGPU_AB

@@ -133,3 +133,39 @@ def test_smart_gpus_rehearsal_on_one_box(tmp_path):
     # without the rehearsal switch more GPUs than the box has is an error, not a silent fallback
     bad = run("smart", "-text", "rand4", "-plen", "2", "2", "-pset", "1", "-gpus", "64", cwd=str(tmp_path))
     assert bad.returncode == 1 and "only" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_smart_times_every_pattern_when_spread_or_bound_are_asked_for(tmp_path, oracle):
+    """src/smart.c:320-329 times every pattern, :337-343 applies -tb per run, :347-351 derives best / worst / std from
+    those times.  With -dif, -std or -tb the harness launches and times every pattern on its own
+    (smartgpu_search_batch64_each) — so ONE deliberately slow pattern in a set shows as the worst time, gives a standard
+    deviation, and trips [OUT] when the bound lies between the fast and the slow ones; without those flags the set
+    shares one grid (texts up to 32 MiB) and only the mean is reported.
+    The corpus: 8 MiB of rand128 followed by 8 MiB of 'a' — a pattern cut from the second half is a candidate at
+    every position of that half for the packed matcher (EPSM verifies each of them in memory), one from the first half
+    is a candidate nowhere else."""
+    import numpy as np
+    d = tmp_path / "data" / "rand128"
+    d.mkdir(parents=True)
+    half = 8 << 20
+    body = np.concatenate([oracle.gen_text(4242, 128, 0, half) + 1, np.full(half, ord("a"), np.uint8)])  # (+1: no NUL bytes)
+    (d / "slow.txt").write_bytes(body.tobytes())
+    (d / "index.txt").write_text("#slow.txt#\n")
+    common = ("smart", "-text", "rand128", "-data", str(tmp_path / "data"), "-tsize", "16", "-plen", "32", "32", "-pset", "12",
+              "-seed", "11", "-algo", "epsm", "-occ")
+    r = run(*common, "-dif", "-std", "-tb", "60000", cwd=str(tmp_path))
+    assert r.returncode == 0 and "[OK]" in r.stdout, r.stdout + r.stderr
+    line = [ln for ln in r.stdout.splitlines() if "] EPSM ." in ln][0]
+    best, worst = (float(x) for x in re.search(r"\[(\d+\.\d+), (\d+\.\d+)\]", line).groups())
+    std = float(re.search(r"std (\d+\.\d+)", line).group(1))
+    assert worst > 4 * best and std > 0, line  # the slow patterns stand out: every pattern was timed on its own
+    # a bound between the fast and the slow patterns: the first slow one ends the algorithm with [OUT] (smart.c:337-343)
+    bound = "%.4f" % ((best * worst) ** 0.5)
+    out = run(*common, "-tb", bound, cwd=str(tmp_path))
+    assert out.returncode == 0 and "[OUT]" in out.stdout and "[OK]" not in out.stdout, (bound, out.stdout)
+    # a bound below the fastest: [OUT] as well; far above the slowest: [OK]
+    assert "[OUT]" in run(*common, "-tb", "%.5f" % (best / 4), cwd=str(tmp_path)).stdout
+    # without the flags: the set shares a grid, the mean is reported
+    plain = run(*common, cwd=str(tmp_path))
+    assert plain.returncode == 0 and "[OK]" in plain.stdout and "std" not in plain.stdout, plain.stdout
