@@ -128,8 +128,8 @@ struct smartgpu_text {
     // what the text consists of, taken once when it is created (text_alphabet below): the byte values that occur, and
     // — for at most four of them — their two-bit codes (ScanArgs.four_shift, four_symtab; 7: none)
     uint32_t alphabet[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t four_shift = 7, four_symtab = 0;
-    sg::TextCodes codes() const { sg::TextCodes c; c.shift = four_shift; c.symtab = four_symtab; return c; }
+    uint32_t four_shift = 7, four_symtab = 0, one_bit = 0xFF;
+    sg::TextCodes codes() const { sg::TextCodes c; c.shift = four_shift; c.symtab = four_symtab; c.one = one_bit; return c; }
 };
 
 struct smartgpu_plan {
@@ -204,9 +204,23 @@ bool text_alphabet(smartgpu_text* t, DeviceCtx* d)
     if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
     if (e != hipSuccess) { set_error("text_alphabet failed: %s", hipGetErrorString(e)); return false; }
     if (!sg::four_symbol_codes(t->alphabet, &t->four_shift, &t->four_symtab)) t->four_shift = 7;
-    // the kernels' copy: the first two words of the allocation (TextCodes, kernels.hpp)
-    const uint32_t words[2] = {t->four_shift, t->four_symtab};
-    if (hipMemcpyAsync(t->base, words, 8, hipMemcpyHostToDevice, d->stream) != hipSuccess ||
+    // one-bit codes of a text of at most two byte values: the lowest bit in which they differ (one value: bit 0)
+    t->one_bit = 0xFF;
+    {
+        uint32_t syms[3], ns = 0;
+        for (uint32_t c = 0; c < 256 && ns < 3; ++c)
+            if (t->alphabet[c >> 5] >> (c & 31) & 1u) syms[ns++] = c;
+        if (ns == 1) syms[ns++] = syms[0];
+        if (ns == 2) {
+            uint32_t bit = 0;
+            while (bit < 7 && ((syms[0] ^ syms[1]) >> bit & 1u) == 0) ++bit;
+            const uint32_t s0 = (syms[0] >> bit & 1u) ? syms[1] : syms[0], s1 = (syms[0] >> bit & 1u) ? syms[0] : syms[1];
+            t->one_bit = bit | (s0 << 8) | (s1 << 16);
+        }
+    }
+    // the kernels' copy: the first three words of the allocation (TextCodes, kernels.hpp)
+    const uint32_t words[3] = {t->four_shift, t->four_symtab, t->one_bit};
+    if (hipMemcpyAsync(t->base, words, 12, hipMemcpyHostToDevice, d->stream) != hipSuccess ||
         hipMemsetAsync(dev, 0, 32, d->stream) != hipSuccess ||  // the pad is zero again
         hipStreamSynchronize(d->stream) != hipSuccess) {
         set_error("text_alphabet: writing the codes failed");
@@ -222,9 +236,10 @@ bool text_no_alphabet(smartgpu_text* t, DeviceCtx* d)
 {
     t->four_shift = 7;
     t->four_symtab = 0;
+    t->one_bit = 0xFF;
     for (uint32_t& wv : t->alphabet) wv = 0xFFFFFFFFu;  // unknown: every byte value may occur
-    const uint32_t words[2] = {7u, 0u};
-    if (hipMemcpyAsync(t->base, words, 8, hipMemcpyHostToDevice, d->stream) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) {
+    const uint32_t words[3] = {7u, 0u, 0xFFu};
+    if (hipMemcpyAsync(t->base, words, 12, hipMemcpyHostToDevice, d->stream) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) {
         set_error("text upload: writing the codes failed");
         return false;
     }

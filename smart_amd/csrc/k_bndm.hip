@@ -27,10 +27,20 @@ namespace sg {
 // 2's loop; English: 2; four symbols: 4; two: 8 — where a loop that reads byte by byte and tests after each walks
 // five to eight dependent LDS round trips deep into nearly every window (rand4 m = 32: 66 %, rand2: 38 %).
 // ---------------------------------------------------------------------------
-template <int THREADS, int L, bool LONG, int Q>  // LONG: m > 32, prefix hits are verified
+// GRAM (round 4) — a TEXT of at most four distinct byte values (TextCodes: what a text consists of is known since it was
+// created).  The Q bytes an iteration reads are then one of 256 grams — Q = 4 symbols of two bits (GRAM = 2), or, on a
+// text of two byte values, Q = 8 symbols of one bit (GRAM = 1) — and the Q mask lookups, shifts and ANDs of the loop
+// above collapse into ONE lookup of G[gram] = AND_i (B[c_i] << i): v_lshrrev, v_and, v_dot4_u32_u8 (the index), the LDS
+// read — 4 vector operations and one LDS read where Q = 4 cost 12 and 4 (Q = 8: 7 and 1 for 24 and 8).  The workgroup
+// derives G from B and the text's codes before it starts (256 entries, Q lookups each).
+// A window that IS one gram (w = Q: 8 bytes on two symbols, 4 on four) needs no state at all: E[gram] holds what BNDM
+// computes for it, occurrence (bit 31) and bndm.c:54's shift `last` (the longest proper suffix of the window that is a
+// prefix of P) — one lookup per window, where the loop above, which forgets what it saw inside a gram, could only move by 1.
+template <int THREADS, int L, bool LONG, int Q, int GRAM = 0>  // LONG: m > 32, prefix hits are verified
 __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_first,
                                                      uint32_t ntiles, const BatchItem* __restrict__ batch)
 {
+    static_assert(GRAM == 0 || (GRAM == 1 && Q == 8) || (GRAM == 2 && Q == 4), "a gram is 8 one-bit or 4 two-bit symbols");
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
     constexpr int TB = THREADS * L;
     using CT = ColTile<THREADS>;  // a window reaches 31 bytes back: the 32 bytes in front of every segment
@@ -38,8 +48,12 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32;
     uint32_t* B = reinterpret_cast<uint32_t*>(smem);
-    constexpr uint32_t kTxt = 1024;
+    constexpr uint32_t kGt = 1024, kEt = 2048;      // GRAM: G[256] and E[256] behind B[256]
+    constexpr uint32_t kTxt = GRAM ? 3072 : 1024;
     uint8_t* txt = smem + kTxt;
+    // GRAM: the text's codes, from the first words of the text's own allocation (TextCodes, kernels.hpp)
+    const uint32_t cshift = GRAM == 2 ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[0]
+                          : GRAM == 1 ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[2] & 0xFFu : 0u;  // two-bit codes: (c >> shift) & 3; one-bit: (c >> bit) & 1
 
     // masks left-aligned (B'[c] = B[c] << (32-w)): D << 1 then drops factors that can no longer become a prefix, instead
     // of carrying dead bits above bit w-1 as bndm.c's 32-bit word does for m < 32 (the next AND clears them either way:
@@ -49,6 +63,29 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
     if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {  // the walk below addresses LDS by offset
         if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
         return;
+    }
+    if (GRAM) {  // G and E from B and the text's codes: entry g for the gram whose byte i has code (g >> (bits * i)) & (2^bits - 1)
+        __syncthreads();
+        const uint32_t symtab = GRAM == 2 ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[1]
+                                          : reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[2] >> 8;  // byte value of each code
+        for (uint32_t g = threadIdx.x; g < 256; g += THREADS) {
+            uint32_t G = 0xFFFFFFFFu, D = 0xFFFFFFFFu, last = w, occ = 0;
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {  // byte Q-1-j of the gram: the j-th byte BNDM reads (right to left)
+                const int i = Q - 1 - j;
+                const uint32_t code = GRAM == 2 ? (g >> (2 * i)) & 3u : (g >> i) & 1u;
+                const uint32_t m_c = B[(symtab >> (8 * code)) & 0xFFu];
+                G &= m_c << i;
+                D &= m_c;                                      // bndm.c:51
+                if ((int32_t)D < 0) {                          // bndm.c:52: the j+1 bytes read are a prefix of P
+                    if ((uint32_t)j + 1 < w) last = w - (j + 1);  // bndm.c:53-54
+                    else occ = 1;                              // bndm.c:55
+                }
+                D <<= 1;                                       // bndm.c:57
+            }
+            reinterpret_cast<uint32_t*>(smem + kGt)[g] = G;
+            reinterpret_cast<uint32_t*>(smem + kEt)[g] = (occ << 31) | last;  // read only when w == Q
+        }
     }
 
     const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
@@ -88,6 +125,34 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
         // m > 32 cells); 2 (LONG, the lanes that saw more than one in this tile — periodic texts) P[32..m) is compared
         // on the spot (bndm.c:99-102).
         uint32_t nocc = 0, last = 0;
+        // the gram the Q bytes in xw are (GRAM): byte i's code in bits [bits * i, bits * (i + 1))
+        auto gram_of = [&](const uint32_t (&xw)[2]) -> uint32_t {
+            if (GRAM == 2) return __builtin_amdgcn_udot4((xw[0] >> cshift) & 0x03030303u, 0x40100401u, 0u, false);
+            const uint32_t lo = __builtin_amdgcn_udot4((xw[0] >> cshift) & 0x01010101u, 0x08040201u, 0u, false);
+            const uint32_t hi = __builtin_amdgcn_udot4((xw[1] >> cshift) & 0x01010101u, 0x08040201u, 0u, false);
+            return lo | (hi << 4);
+        };
+        if (GRAM != 0 && !LONG && w == (uint32_t)Q) {  // (uniform) the window is one gram: a lookup per window, no state
+            uint32_t e = 32u + x0;
+            const uint32_t ehi = 32u + x1;
+            while (e < ehi) {
+                const uint32_t pl = e - (Q - 1);
+                const uint32_t at = col4 + (pl >> 2) * CT::RS;
+                const uint32_t w0 = *(const lds_u32_t*)(size_t)at;
+                const uint32_t w1 = *(const lds_u32_t*)(size_t)(at + CT::RS);
+                uint32_t xw[2];
+                xw[0] = __builtin_amdgcn_alignbyte(w1, w0, pl);
+                xw[1] = 0u;
+                if (Q == 8) {
+                    const uint32_t w2 = *(const lds_u32_t*)(size_t)(at + 2 * CT::RS);
+                    xw[1] = __builtin_amdgcn_alignbyte(w2, w1, pl);
+                }
+                const uint32_t ent = *(const lds_u32_t*)(size_t)(kEt + 4u * gram_of(xw));
+                hits += ent >> 31;
+                e += ent & 0xFFu;
+            }
+            continue;  // next tile
+        }
         auto walk = [&](auto how) {
             constexpr int HOW = decltype(how)::value;
             uint32_t e = 32u + x0, k = 0, D = 0xFFFFFFFFu;
@@ -111,11 +176,15 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
                     }
                 }
                 uint32_t G = 0xFFFFFFFFu;
+                if (GRAM) {
+                    G = *(const lds_u32_t*)(size_t)(kGt + 4u * gram_of(xw));  // the Q masks, shifted and ANDed, ready-made
+                } else {
 #pragma unroll
-                for (int j = 0; j < Q; ++j) {  // step j reads byte Q-1-j; its mask meets D after Q-1-j more shifts
-                    const int i = Q - 1 - j;
-                    const uint32_t c = (xw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                    G &= *(const lds_u32_t*)(size_t)(4u * c) << i;  // B[c]
+                    for (int j = 0; j < Q; ++j) {  // step j reads byte Q-1-j; its mask meets D after Q-1-j more shifts
+                        const int i = Q - 1 - j;
+                        const uint32_t c = (xw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                        G &= *(const lds_u32_t*)(size_t)(4u * c) << i;  // B[c]
+                    }
                 }
                 const uint32_t tt = (D << (Q - 1)) & G;  // bndm.c:51, Q times
                 const uint32_t kq = k + Q;
@@ -161,13 +230,26 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
 // with SIX (four: 0.202 / 0.165 / 0.214).  Two-wave workgroups (tune(2,2)) were never ahead: 8 of them
 // 0.190 / 0.171 / 0.200 on the small alphabets, 0.177 / 0.172 / 0.180 on English.
 // ---------------------------------------------------------------------------
-hipError_t launch_bndm(const ScanArgs& a, int num_cus, hipStream_t stream)
+hipError_t launch_bndm(const ScanArgs& a, int num_cus, hipStream_t stream, TextCodes codes)
 {
     const uint32_t m = a.m, w = m < 32 ? m : 32;
-    uint32_t q = g_tune[1] ? (uint32_t)g_tune[1] : a.halo;  // tune(1, q): experiments
+    uint32_t q = (g_tune[1] && g_tune[1] != 9) ? (uint32_t)g_tune[1] : a.halo;  // tune(1, q): experiments (9: the plan's q, no gram table)
     while (q > 1 && w % q) q /= 2;
     const bool two_wave = g_tune[2] == 2;
     const int wgs = a.sparse ? 4 : q >= 4 ? 6 : 5;
+    // A text of at most four byte values: the gram table (the kernel's comment).  Eight one-bit symbols per step on two
+    // values, four two-bit symbols on three or four; the window must be whole grams.  tune(1, 9): never (A/B).
+    const int gram = g_tune[1] == 9 ? 0 : ((codes.one & 0xFFu) != 0xFFu && w % 8 == 0) ? 1 : (codes.shift < 7 && w % 4 == 0) ? 2 : 0;
+    if (gram) {
+        const size_t lds = 3072 + ColTile<kBndmT>::bytes();
+        const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
+        if (gram == 1) {
+            if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, 8, 1>, a, tr, kBndmT, lds, 6, num_cus, stream);
+            return launch_tiled(bndm_scan<kBndmT, kBndmL, false, 8, 1>, a, tr, kBndmT, lds, 6, num_cus, stream);
+        }
+        if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, 4, 2>, a, tr, kBndmT, lds, 6, num_cus, stream);
+        return launch_tiled(bndm_scan<kBndmT, kBndmL, false, 4, 2>, a, tr, kBndmT, lds, 6, num_cus, stream);
+    }
 #define SG_BNDM(T_, WGS_, Q_)                                                                            \
     do {                                                                                                  \
         const size_t lds = 1024 + ColTile<T_>::bytes();                                                   \

@@ -60,7 +60,10 @@ struct ScanArgs {
 // kXSize + 256 bytes and more).  Neither members of ScanArgs nor kernel arguments: two more words in either changed
 // the register allocation and the schedule of kernels whose source had not changed — hor_scan ran 5-6 % slower with
 // them in ScanArgs, kmp_runs<false, false> 3-9 % slower with them as its own arguments (build against build).
-struct TextCodes { uint32_t shift = 7, symtab = 0; };
+// `one` (round 4; the third word of the text's allocation): a text of at most TWO byte values also has one-bit codes —
+// bits 0-7: the bit that tells the two apart (0xFF: more than two values), bits 8-15 / 16-23: the value whose bit is 0 / 1
+// (bndm_scan<.., GRAM = 1>: eight symbols per table step).
+struct TextCodes { uint32_t shift = 7, symtab = 0, one = 0xFF; };
 
 // One pattern of a set that runs as ONE grid (launch_scan_set): what differs from pattern to pattern.  Everything
 // else — text, range, m — and the BASES of the table arena and of the count array come from the by-value ScanArgs.

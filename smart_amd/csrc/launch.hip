@@ -217,7 +217,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
         case SMARTGPU_BNDM:
             if ((m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1) || pk) return launch_packed(SMARTGPU_BNDM, a, num_cus, stream);
             if (algo == SMARTGPU_SBNDM) return launch_sbndm(a, num_cus, stream);
-            return launch_bndm(a, num_cus, stream);
+            return launch_bndm(a, num_cus, stream, codes);
         case SMARTGPU_SA:  // Shift-And counts in the complemented, Shift-Or form (api.cpp build_blob); its own AND form
         case SMARTGPU_SO: {  // (so_runs1<.., AND = true>, masks after the Shift-Or ones) is in the A/B build: tune(6,3)
 #ifdef SMARTGPU_AB

@@ -155,7 +155,7 @@ hipError_t launch_hor_bp(const ScanArgs& a, int num_cus, hipStream_t stream);   
 // k_bm.hip
 hipError_t launch_bm(const ScanArgs& a, int num_cus, hipStream_t stream);
 // k_bndm.hip, k_bndmx.hip
-hipError_t launch_bndm(const ScanArgs& a, int num_cus, hipStream_t stream);
+hipError_t launch_bndm(const ScanArgs& a, int num_cus, hipStream_t stream, TextCodes codes);
 hipError_t launch_sbndm(const ScanArgs& a, int num_cus, hipStream_t stream);
 hipError_t launch_bndml(const ScanArgs& a, int num_cus, hipStream_t stream);
 // k_so.hip, k_kmp.hip

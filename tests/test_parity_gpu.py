@@ -313,7 +313,7 @@ def test_small_alphabets_dense_matches(oracle):
 
 def test_two_symbol_patterns_count_on_shift_or_runs_and_on_their_own_kernels(oracle):
     """A pattern of 16+ bytes over two or three symbols is counted by so_runs whatever the algorithm
-    (api.cpp build_blob / kernels.hip launch_scan); tune(0,1) keeps every algorithm on its own kernel.
+    (api.cpp build_blob / launch.hip launch_scan); tune(0,1) keeps every algorithm on its own kernel.
     Both must give the oracle's count; patterns over larger alphabets are not rerouted."""
     from smart_amd import engine
     own = ("kmp", "kr")
@@ -329,6 +329,8 @@ def test_two_symbol_patterns_count_on_shift_or_runs_and_on_their_own_kernels(ora
                     pl = Plan(a, P)
                     if a == "bndm" or (a == "bndml" and m <= 32):  # round 3: bndm_scan reads 8 bytes of a 32-byte window per step
                         assert pl.kernel_name == ("bndm_scan" if m >= 32 else "so_runs"), (a, m, pl.kernel_name)
+                    elif a == "hor":  # round 4: Horspool's q-gram bad-character table (q = 8 on two symbols) from 64 bytes on
+                        assert pl.kernel_name == ("hor_scan" if m >= 64 and len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
                     else:
                         assert (pl.kernel_name == "so_runs") == (a not in own), (a, m, pl.kernel_name)
                     pl.free()
@@ -664,6 +666,71 @@ def test_kmp_four_bytes_per_step(oracle):
     engine.tune(0, 1)
     try:
         assert smart_amd.search("kmp", np.frombuffer(b"ACGTNACGT", dtype=np.uint8), text)[0] == 0
+    finally:
+        engine.tune(0, 0)
+    text.free()
+
+
+def test_bndm_gram_tables_on_texts_of_at_most_four_values(oracle):
+    """bndm_scan<.., GRAM> (round 4): on a text of at most four distinct byte values an iteration's Q bytes are one of 256
+    grams — four two-bit symbols, or eight one-bit symbols on two values — and ONE lookup in a table the workgroup derives
+    from the masks and the text's codes replaces the Q mask lookups; a window that is a single gram (8 bytes on two values,
+    4 on four) takes bndm.c's occurrence flag and shift from a second table.  Against the oracle and against the mask loop
+    (tune(1,9)): byte values that are not 0..3 (ACGT, 0 / 255, one value), planted, overlapping and periodic occurrences,
+    windows of one, two and eight grams, lengths that are no whole grams (the mask loop), m > 32 (prefix + verification),
+    a fifth value in the text (no gram table), patterns with symbols the text does not hold, sub-ranges, BNDML's m <= 32."""
+    from smart_amd import engine
+    rng = np.random.default_rng(16)
+    n = 2 << 20
+    alphabets = {"01": [0, 1], "acgt": list(b"ACGT"), "far": [0, 255], "one": [7], "three": [1, 2, 200], "odd": [3, 5]}
+    for name, values in alphabets.items():
+        vals = np.asarray(values, dtype=np.uint8)
+        for m in (4, 8, 12, 16, 20, 24, 32, 33, 40, 64, 300):
+            T = vals[oracle.gen_text(991 + m, max(len(values), 2), 0, n) % len(values)]
+            P = T[150_000:150_000 + m].copy()
+            if m in (8, 24):
+                P[:] = np.resize(P[:3], m)           # a period of three: overlapping occurrences, borders
+            for k in rng.integers(0, n - m, 200):
+                T[k:k + m] = P
+            T[:m] = P
+            T[n - m:] = P
+            if m == 20 and len(values) > 1:
+                T[1000:1000 + 3 * m] = np.resize(P, 3 * m)  # back to back
+            text = Text.upload(T)
+            assert len(text.alphabet()) <= 4
+            want = oracle.search("bndm", P, T)
+            assert want >= 100 or name == "one"
+            sub_want = oracle.search("bf", P, T[54_321:54_321 + 1_000_001])
+            engine.tune(0, 1)  # bndm_scan itself at any length
+            try:
+                for a in ("bndm", "bndml") if m <= 32 else ("bndm",):
+                    assert smart_amd.kernel_for(a, P) == "bndm_scan"
+                    got = smart_amd.search(a, P, text)[0]
+                    engine.tune(1, 9)  # the mask loop on the same plan
+                    plain = smart_amd.search(a, P, text)[0]
+                    engine.tune(1, 0)
+                    assert got == want and plain == want, (name, m, a, got, plain, want)
+                    assert smart_amd.search(a, P, text, off=54_321, n=1_000_001)[0] == sub_want, (name, m, a)
+                # a pattern set in one grid (texts up to 32 MiB): the grams of every pattern of the set
+                pats = [P, T[77:77 + m].copy(), T[999_999:999_999 + m].copy()]
+                counts, _, _, _ = smart_amd.search_batch("bndm", pats, text)
+                assert counts.tolist() == [oracle.search("bf", p, T) for p in pats], (name, m)
+                # a symbol the text does not hold: no occurrence, whatever the tables say about codes that are not in use
+                Q = P.copy()
+                Q[m // 2] = 99
+                assert smart_amd.search("bndm", Q, text)[0] == 0, (name, m)
+            finally:
+                engine.tune(1, 0)
+                engine.tune(0, 0)
+            text.free()
+    # a fifth value: the text has no codes, the mask loop runs
+    T = np.asarray(list(b"ACGT"), dtype=np.uint8)[oracle.gen_text(31, 4, 0, n)]
+    T[rng.integers(0, n, 1000)] = ord("N")
+    P = T[5000:5016].copy()
+    text = Text.upload(T)
+    engine.tune(0, 1)
+    try:
+        assert smart_amd.search("bndm", P, text)[0] == oracle.search("bf", P, T)
     finally:
         engine.tune(0, 0)
     text.free()
