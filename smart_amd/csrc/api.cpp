@@ -553,7 +553,15 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
         // ... unless Horspool has its q-gram table for them and a window long enough for its shifts (within 5-10 points of so_runs)
         if (hor_q) own_holds = distinct <= 2 ? m >= 64 : m >= 32;
         if (algo == SMARTGPU_BNDM || (algo == SMARTGPU_BNDML && m <= 32)) own_holds = *halo == bndm_q_wanted && (*halo >= 8 ? m >= 32 : m >= 16);  // *halo: bndm_scan's q
-        if (own_holds && m > sg::short_pattern_max_m(algo)) {
+        // BNDM, eight bytes over two symbols: on a text of two byte values the window is ONE gram of bndm_scan<.., GRAM = 1> —
+        // occurrence and shift from one lookup per window, 0.74 of the roofline on rand2 (its mask loop there: 0.20; so_runs
+        // 0.78).  The plan cannot see the text; a pattern of two symbols cut from it says what it most likely is.
+        const bool gram_window = (algo == SMARTGPU_BNDM || algo == SMARTGPU_BNDML) && m == 8 && distinct == 2;
+        if (gram_window) {
+            *halo |= sg::kBndmGramWindow;
+            to_so = false;
+            *prefer_packed = 0;
+        } else if (own_holds && m > sg::short_pattern_max_m(algo)) {
             to_so = false;
             *prefer_packed = 0;
         } else if (!to_so && m >= 8) {  // (8 bytes of distinct symbols estimate 16/8^4 = 0.004: below that the histogram says nothing)
@@ -842,7 +850,7 @@ int smartgpu_plan_result(smartgpu_plan* p, int slot, uint64_t* count, double* ke
 
 const char* smartgpu_plan_kernel_name(const smartgpu_plan* p)
 {
-    return p ? sg::scan_kernel_name(p->algo, p->m, p->prefer_packed != 0, p->so_off != 0) : nullptr;
+    return p ? sg::scan_kernel_name(p->algo, p->m, p->prefer_packed != 0, p->so_off != 0, p->halo) : nullptr;
 }
 
 const char* smartgpu_kernel_for(int algo, const uint8_t* P, uint32_t m)
@@ -853,7 +861,7 @@ const char* smartgpu_kernel_for(int algo, const uint8_t* P, uint32_t m)
     }
     uint32_t halo = 0, prefer_packed = 0, sparse = 0, so_off = 0;
     (void)build_blob(algo, P, m, &halo, &prefer_packed, &sparse, &so_off);
-    return sg::scan_kernel_name(algo, m, prefer_packed != 0, so_off != 0);
+    return sg::scan_kernel_name(algo, m, prefer_packed != 0, so_off != 0, halo);
 }
 
 void* smartgpu_plan_result_device_ptr(smartgpu_plan* p) { return p ? p->slot_ptr(0) : nullptr; }
@@ -1123,8 +1131,8 @@ int batch_enqueue(DeviceCtx* d, int algo, const std::vector<BatchPlan>& plans, u
     const bool halo_is_q = algo == SMARTGPU_BNDM || algo == SMARTGPU_BNDML;
     auto key = [&](uint32_t k) {
         const uint32_t pp = algo == SMARTGPU_KMP ? plans[k].prefer_packed : (plans[k].prefer_packed ? 1u : 0u);
-        const uint32_t variant = halo_is_q ? plans[k].halo & 0xFFu : algo == SMARTGPU_HOR ? (plans[k].halo >> 8) & 0xFFu : 0u;
-        return (static_cast<uint64_t>(pp) << 16) | (variant << 8) | (plans[k].so_off ? 2u : 0u) | (plans[k].sparse ? 1u : 0u);
+        const uint32_t variant = halo_is_q ? plans[k].halo & 0x1FFu : algo == SMARTGPU_HOR ? (plans[k].halo >> 8) & 0xFFu : 0u;  // BNDM: q and the gram-window mark
+        return (static_cast<uint64_t>(pp) << 20) | (variant << 8) | (plans[k].so_off ? 2u : 0u) | (plans[k].sparse ? 1u : 0u);
     };
     std::vector<uint32_t> order(K);
     for (uint32_t k = 0; k < K; ++k) order[k] = k;

@@ -48,8 +48,11 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32;
     uint32_t* B = reinterpret_cast<uint32_t*>(smem);
-    constexpr uint32_t kGt = 1024, kEt = 2048;      // GRAM: G[256] and E[256] behind B[256]
-    constexpr uint32_t kTxt = GRAM ? 3072 : 1024;
+    // GRAM: the table of the grams — G, or E where the window is one gram — takes B's place once it is derived from it
+    // (the loop reads only the one; a kilobyte more per workgroup and the sixth workgroup no longer fits the CU: a
+    // tail round, +10 % — measured)
+    constexpr uint32_t kGt = 0, kEt = 0;
+    constexpr uint32_t kTxt = 1024;
     uint8_t* txt = smem + kTxt;
     // GRAM: the text's codes, from the first words of the text's own allocation (TextCodes, kernels.hpp)
     const uint32_t cshift = GRAM == 2 ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[0]
@@ -68,7 +71,10 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
         __syncthreads();
         const uint32_t symtab = GRAM == 2 ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[1]
                                           : reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[2] >> 8;  // byte value of each code
-        for (uint32_t g = threadIdx.x; g < 256; g += THREADS) {
+        static_assert(GRAM == 0 || THREADS == 256, "thread g derives entry g, then all overwrite B together");
+        const uint32_t g = threadIdx.x;
+        uint32_t entry;
+        {
             uint32_t G = 0xFFFFFFFFu, D = 0xFFFFFFFFu, last = w, occ = 0;
 #pragma unroll
             for (int j = 0; j < Q; ++j) {  // byte Q-1-j of the gram: the j-th byte BNDM reads (right to left)
@@ -83,9 +89,10 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
                 }
                 D <<= 1;                                       // bndm.c:57
             }
-            reinterpret_cast<uint32_t*>(smem + kGt)[g] = G;
-            reinterpret_cast<uint32_t*>(smem + kEt)[g] = (occ << 31) | last;  // read only when w == Q
+            entry = (!LONG && w == (uint32_t)Q) ? (occ << 31) | last : G;  // E where the window is one gram, else G
         }
+        __syncthreads();  // every thread has read B
+        B[g] = entry;
     }
 
     const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
@@ -241,7 +248,7 @@ hipError_t launch_bndm(const ScanArgs& a, int num_cus, hipStream_t stream, TextC
     // values, four two-bit symbols on three or four; the window must be whole grams.  tune(1, 9): never (A/B).
     const int gram = g_tune[1] == 9 ? 0 : ((codes.one & 0xFFu) != 0xFFu && w % 8 == 0) ? 1 : (codes.shift < 7 && w % 4 == 0) ? 2 : 0;
     if (gram) {
-        const size_t lds = 3072 + ColTile<kBndmT>::bytes();
+        const size_t lds = 1024 + ColTile<kBndmT>::bytes();
         const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
         if (gram == 1) {
             if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, 8, 1>, a, tr, kBndmT, lds, 6, num_cus, stream);

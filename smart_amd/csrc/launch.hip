@@ -92,7 +92,7 @@ static int hor_regime(uint32_t m, int algo = SMARTGPU_HOR)
     return m <= packed_max_m(algo) ? 3 : 1;  // bank-private kernel: only on request
 }
 
-const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_masks)
+const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_masks, uint32_t halo)
 {
 #ifdef SMARTGPU_AB
     const char* const so_name = g_tune[6] == 1 ? "so_scan" : g_tune[6] == 2 ? "so_runs64" : g_tune[6] == 4 ? "so_runs1" : "so_runs";
@@ -127,7 +127,9 @@ const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_m
             if (m > 32) return pk ? "packed_scan" : "bndml_scan";
             [[fallthrough]];
         case SMARTGPU_SBNDM:
-        case SMARTGPU_BNDM: return (pk || (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1)) ? "packed_scan" : algo == SMARTGPU_SBNDM ? "sbndm_scan" : "bndm_scan";
+        case SMARTGPU_BNDM:
+            if (algo != SMARTGPU_SBNDM && (halo & kBndmGramWindow) && !pk) return "bndm_scan";  // a one-gram window (api.cpp)
+            return (pk || (m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1)) ? "packed_scan" : algo == SMARTGPU_SBNDM ? "sbndm_scan" : "bndm_scan";
         case SMARTGPU_EPSM: return "packed_scan";
     }
     return "?";
@@ -142,9 +144,15 @@ ScanArgs prepare_scan_args(int algo, ScanArgs a)
     switch (algo) {
         case SMARTGPU_KR: a.fp_off = kTableOff + 4; break;  // after the pattern's hash
         case SMARTGPU_BM: a.fp_off = kTableOff + ((1536 + 2 * (m + 1) + 3) & ~3u); break;  // after first, second, bc, gs, safe shift
-        case SMARTGPU_BNDML: a.fp_off = m > 32 ? kTableOff + 1024 * 2 + 4 : kTableOff + 1024; break;  // after the masks (W = 2) and the period / after B[256]
+        case SMARTGPU_BNDML:  // after the masks (W = 2) and the period / after B[256]
+            a.fp_off = m > 32 ? kTableOff + 1024 * 2 + 4 : kTableOff + 1024;
+            a.halo &= 0xFFu;
+            break;
         case SMARTGPU_SBNDM:
-        case SMARTGPU_BNDM: a.fp_off = kTableOff + 1024; break;  // after B[256]
+        case SMARTGPU_BNDM:  // after B[256]; halo = bndm_scan's q, the plan's marks above it
+            a.fp_off = kTableOff + 1024;
+            a.halo &= 0xFFu;
+            break;
         case SMARTGPU_EPSM: a.fp_off = kTableOff; break;
         case SMARTGPU_SO: a.so_off = kTableOff; break;
         case SMARTGPU_SA: a.so_off = g_tune[6] == 3 ? kTableOff + 1024 : kTableOff; break;
@@ -215,6 +223,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
             [[fallthrough]];
         case SMARTGPU_SBNDM:
         case SMARTGPU_BNDM:
+            if (algo != SMARTGPU_SBNDM && (a_in.halo & kBndmGramWindow) && !pk) return launch_bndm(a, num_cus, stream, codes);  // a one-gram window
             if ((m <= packed_max_m(SMARTGPU_BNDM) && g_tune[0] != 1) || pk) return launch_packed(SMARTGPU_BNDM, a, num_cus, stream);
             if (algo == SMARTGPU_SBNDM) return launch_sbndm(a, num_cus, stream);
             return launch_bndm(a, num_cus, stream, codes);

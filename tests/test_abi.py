@@ -318,6 +318,9 @@ def test_kernel_choice_follows_the_pattern(oracle):
             want = {"kmp": "kmp_runs", "kr": "hor_scan_bp", "bndm": "bndm_scan" if m >= 32 else "so_runs", "hor": "hor_scan" if m >= 64 else "so_runs"}.get(a, "so_runs")
             assert kf(a, two[:m]) == want, (a, m)
     assert kf("hor", two[:12]) == "so_runs" and kf("epsm", two[:12]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"
+    # round 4: eight bytes over two symbols are ONE gram of bndm_scan's gram table on a text of two byte values
+    assert len(set(two[:8].tolist())) == 2 and kf("bndm", two[:8]) == "bndm_scan" and kf("bndml", two[:8]) == "bndm_scan"
+    assert kf("bndm", rnd[:8]) == "so_runs" and kf("bndm", four[:8]) == "so_runs" and kf("sbndm", two[:8]) == "so_runs"
     # ... and, since so_runs runs at 75-81 %, on four: EPSM from 8 bytes on (the skip algorithms are there by rule 1)
     assert kf("epsm", four[:8]) == "so_runs" and kf("epsm", four[:64]) == "so_runs" and kf("epsm", four[:4]) == "packed_scan"
     eight = oracle.gen_text(9, 8, 0, 5000)
