@@ -29,7 +29,10 @@ constexpr uint32_t kKmpPrefix = 62;
 constexpr uint32_t kmp_window(uint32_t m) { return m <= kKmpWindow ? m : kKmpPrefix; }
 // kmp_runs<., false, COMPACT>: the automaton of the pattern or of its 56-byte prefix in a compact table — five four-wave
 // workgroups per CU, each with its own copy (launch_common.hpp, k_kmp.hip)
-constexpr uint32_t kKmpCompactWindow = 56;  // 60 fits five workgroups into 160 KB on paper (162,640 bytes) and ran as four + a tail round: 0.24 ms where 0.19 was due
+#ifndef SMARTGPU_KMP_COMPACT_WINDOW
+#define SMARTGPU_KMP_COMPACT_WINDOW 56  // (a macro so that tools/build_variant.sh can build other windows for an A/B)
+#endif
+constexpr uint32_t kKmpCompactWindow = SMARTGPU_KMP_COMPACT_WINDOW;  // 60 fits five workgroups into 160 KB on paper (162,640 bytes) and ran as four + a tail round: 0.24 ms where 0.19 was due
 constexpr uint32_t kmp_compact_window(uint32_t m) { return m < kKmpCompactWindow ? m : kKmpCompactWindow; }
 constexpr uint32_t kKmpQBytes = 272;   // kmp_runs: after the transitions, Q[s] = P[s..s+4) for 64 states (LDS), thr = 4K, 12 bytes of padding
 constexpr uint32_t kKmpDfaMaxM = 255;  // KMP: the automaton's states are u8, so its (w+1)*256-byte transition

@@ -12,7 +12,7 @@ for u in k_hor k_bm k_bndm k_bndmx k_so k_kmp k_packed k_util launch; do
   /opt/rocm/bin/hipcc $FLAGS "$@" --offload-arch=gfx950 -c -o $T/$u.o $D/$u.hip &
 done
 /opt/rocm/bin/hipcc $FLAGS "$@" --offload-arch=gfx950 -c -o $T/api.o $D/api.cpp &
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -c -o $T/tables.o $D/tables.cpp &
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC "$@" -c -o $T/tables.o $D/tables.cpp &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $D/libsmartgpu_$NAME.so $T/*.o -ldl
 rm -rf $T
