@@ -423,6 +423,7 @@ def main():
                                % (K, "/".join(sorted(set(others))), " and the CPU sample" if cpu else ""),
         }
         if sweep is not None:
+            out["roofline_secondary"] = sweep["roofline_secondary"]
             out["min_frac"] = sweep["min_frac"]
             out["own_kernel_min"] = sweep["own_kernel_min"]
             out["worst_cells"] = sweep["worst_cells"]
@@ -451,7 +452,7 @@ def compact_line(out, limit=LINE_LIMIT):
     are never dropped."""
     out = json.loads(json.dumps(out))  # deep copy
     drops = [("roofline", "kernel_ms_per_pattern"), ("roofline", "traffic_source"), ("config", "prewarm"),
-             ("config", "corpus"), ("config", "sharding"), ("cpu_baseline", "all_cores"), ("rccl", "devices"), ("own_kernel_min",),
+             ("config", "corpus"), ("config", "sharding"), ("cpu_baseline", "all_cores"), ("rccl", "devices"), ("roofline_secondary", "cells"), ("own_kernel_min",),
              ("roofline", "kernels_of_the_timed_plans"), ("counts_verified",), ("worst_cells",), ("min_frac",)]
     line = json.dumps(out, separators=(",", ":"))
     for path in drops:
@@ -489,6 +490,27 @@ def own_kernel_summary(cells):
                 entry[label] = [w["frac"], "%s/m%d" % (w["sigma"], w["m"]), min(long_) if long_ else None]
         out[algo] = entry
     return out
+
+
+def runs_data_path_summary(cells):
+    """The second roofline of the runs kernels: their loader's DATA PATH.  kmp_runs and so_runs move the text the same
+    way — whole 128-byte lines of 64 runs per wave through 4 KB LDS slabs — and that path alone (automaton compiled out)
+    runs at 78-80 % of 8 TB/s; so_runs sits within 2 % of it on every input, so its time on the same
+    text and pattern length, measured in the same sweep, is the live stand-in for that ceiling.  Reported for kmp_runs —
+    the kernel furthest below the HBM roofline among the plans' choices — on the configuration-2 cells both ran:
+    achieved / peak in GB/s, frac = kmp_runs' share of the data path."""
+    pairs = []
+    for c in cells:
+        if c["config"] == 2 and c["algo"] == "kmp" and c["kernel"] == "kmp_runs" and not c.get("own_kernel"):
+            so = [x for x in cells if x["config"] == 2 and x["algo"] == "so" and x["m"] == c["m"] and x["kernel"] == "so_runs"]
+            if so:
+                pairs.append((c["m"], c["frac"], so[0]["frac"]))
+    if not pairs:
+        return None
+    m, kmp, so = min(pairs, key=lambda t: t[1] / t[2])
+    return {"kernel": "kmp_runs", "bound": "runs loader data path (so_runs, same text and m, same sweep)", "workload": "rand128 1 GiB m=%d" % m,
+            "achieved": round(kmp * HBM_PEAK_GBS, 1), "peak": round(so * HBM_PEAK_GBS, 1), "unit": "GB/s", "frac": round(kmp / so, 4),
+            "cells": [[mm, k, s_] for mm, k, s_ in pairs]}
 
 
 def worst_cells_summary(cells, k=3):
@@ -621,6 +643,7 @@ def run_sweep(text128, device):
     north = [c["frac"] for c in cells if c["config"] == 2 and not c.get("own_kernel")]
     plan = lambda k: [c["frac"] for c in cells if c["config"] == k and not c.get("own_kernel")]  # noqa: E731
     return {"cells": cells, "own_kernel_min": own_kernel_summary(cells), "worst_cells": worst_cells_summary(cells),
+            "roofline_secondary": runs_data_path_summary(cells),
             "min_frac": {"rand128_m4to256_plan_choice": min(north),
                          "config3_plan_choice": min(plan(3)), "config4_english_plan_choice": min(plan(4)),
                          "config5_plan_choice": min(plan(5)),
