@@ -553,10 +553,11 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
         // ... unless Horspool has its q-gram table for them and a window long enough for its shifts (within 5-10 points of so_runs)
         if (hor_q) own_holds = distinct <= 2 ? m >= 64 : m >= 32;
         if (algo == SMARTGPU_BNDM || (algo == SMARTGPU_BNDML && m <= 32)) own_holds = *halo == bndm_q_wanted && (*halo >= 8 ? m >= 32 : m >= 16);  // *halo: bndm_scan's q
-        // BNDM, eight bytes over two symbols: on a text of two byte values the window is ONE gram of bndm_scan<.., GRAM = 1> —
-        // occurrence and shift from one lookup per window, 0.74 of the roofline on rand2 (its mask loop there: 0.20; so_runs
-        // 0.78).  The plan cannot see the text; a pattern of two symbols cut from it says what it most likely is.
-        const bool gram_window = (algo == SMARTGPU_BNDM || algo == SMARTGPU_BNDML) && m == 8 && distinct == 2;
+        // BNDM over two to four symbols, 8+ bytes: on a text of at most four byte values bndm_scan's GRAM form decides every
+        // window with one lookup (k_bndm.hip bndm_gram: 0.74-0.8 of the roofline on rand2 / rand4 at any such length; so_runs
+        // 0.77).  The plan cannot see the text; a pattern of two to four symbols cut from it says what it most likely is
+        // (on any other text the launch falls back to the mask loop — correct, and slow on such a pattern).
+        const bool gram_window = (algo == SMARTGPU_BNDM || (algo == SMARTGPU_BNDML && m <= 32)) && m >= 8 && distinct >= 2 && distinct <= 4;
         if (gram_window) {
             *halo |= sg::kBndmGramWindow;
             to_so = false;

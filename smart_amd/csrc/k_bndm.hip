@@ -6,6 +6,146 @@
 namespace sg {
 
 // ---------------------------------------------------------------------------
+// BNDM on a TEXT of at most four distinct byte values (round 4; TextCodes: what a text consists of is known since it
+// was created): the window's last Q bytes are one of 256 GRAMS — Q = 8 one-bit symbols on a text of two values (GRAM = 1),
+// Q = 4 two-bit symbols on three or four (GRAM = 2) — and what bndm.c:44-60 computes from them is a function of the gram
+// alone, tabulated by the workgroup before it starts (256 entries, Q steps of the recurrence each, from B and the text's
+// codes):
+//   * D after the Q steps lists every place i where the gram is a factor of P (bit 31 - i <=> gram == P[i..i+Q));
+//   * the factor at i = w - Q is the window's own place: a CANDIDATE (the whole window if w == Q);
+//   * the nearest factor to its left, i_max, is the smallest shift that can align the gram with P again: w - Q - i_max;
+//     with no factor at all the shift is bndm.c:54's `last` — w minus the longest suffix of the gram that is a prefix of
+//     P (the prefix hits of steps 1..Q-1) — or w.
+// E[gram] = candidate << 31 | shift: ONE lookup per WINDOW — no state between windows, no second iteration: a window
+// whose first gram is alive is not read further unless it is a candidate (then the w - Q bytes before the gram are
+// compared with P[0..w-Q) in LDS; m > 32: the rest in memory, first candidate of a tile parked for wave_verify).  The
+// mask loop below reads on while factors are alive and, forgetting what it saw inside a gram, moves a fully read
+// window by 1 — the lanes that meet such windows set their wave's trip count (rand2 m = 16: 0.35, here the shift is ~14).
+// LDS: u32 E[256] (first B: the masks, left-aligned) | P[0..32) | column tile
+// ---------------------------------------------------------------------------
+template <int THREADS, int L, bool LONG, int Q, int GRAM>
+__device__ __forceinline__ void bndm_gram(const ScanArgs& a, uint64_t tile_first, uint32_t ntiles, uint8_t* smem)
+{
+    constexpr int TB = THREADS * L;
+    using CT = ColTile<THREADS>;
+    static_assert(L == 64 && THREADS == 256 && ((GRAM == 1 && Q == 8) || (GRAM == 2 && Q == 4)), "a gram is 8 one-bit or 4 two-bit symbols; thread g derives entry g");
+    const uint32_t m = a.m, w = m < 32 ? m : 32;  // w >= Q (launch_bndm)
+    uint32_t* E = reinterpret_cast<uint32_t*>(smem);
+    constexpr uint32_t kPat = 1024, kTxt = 1056;
+    uint8_t* txt = smem + kTxt;
+    // the text's codes, from the first words of the text's own allocation (TextCodes, kernels.hpp)
+    const uint32_t* const tc = reinterpret_cast<const uint32_t*>(a.text - kFrontPad);
+    const uint32_t cshift = GRAM == 2 ? tc[0] : tc[2] & 0xFFu;  // two-bit codes: (c >> shift) & 3; one-bit: (c >> bit) & 1
+    const uint32_t symtab = GRAM == 2 ? tc[1] : tc[2] >> 8;     // the byte value of each code
+    E[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.blob + kTableOff)[threadIdx.x] << (32 - w);  // B, left-aligned
+    if (threadIdx.x < 8) reinterpret_cast<uint32_t*>(smem + kPat)[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.blob)[threadIdx.x];
+    if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {  // the walk below addresses LDS by offset
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
+        return;
+    }
+    __syncthreads();
+    {
+        const uint32_t g = threadIdx.x;
+        uint32_t D = 0xFFFFFFFFu, part = 0;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {  // byte Q-1-j of the gram: the j-th byte bndm.c:50 reads (right to left)
+            const int i = Q - 1 - j;
+            const uint32_t code = GRAM == 2 ? (g >> (2 * i)) & 3u : (g >> i) & 1u;
+            D &= E[(symtab >> (8 * code)) & 0xFFu];           // bndm.c:51
+            if (j + 1 < Q) {
+                if ((int32_t)D < 0) part = (uint32_t)j + 1;  // bndm.c:52-54: these j+1 bytes are a prefix of P
+                D <<= 1;                                      // bndm.c:57
+            }
+        }
+        const uint32_t own = 31u - (w - Q);                   // bit of the factor at i = w - Q
+        const uint32_t cand = (D >> own) & 1u;
+        const uint32_t left = own == 31u ? 0u : D >> (own + 1u) << (own + 1u);  // the factors at i < w - Q
+        const uint32_t shift = left ? (w - Q) - (31u - (uint32_t)__builtin_ctz(left)) : w - part;
+        __syncthreads();  // every thread has read B
+        E[g] = (cand << 31) | shift;
+    }
+
+    const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
+    uint32_t hits = 0;
+    uint4 pre[4], ph;  // prefetch registers: 4 tile rows + (threads 0, 1) the 32 bytes in front of the tile
+    auto issue = [&](uint64_t tile0) {
+        const uint8_t* src = a.text + tile0 + threadIdx.x * 16u;
+        pre[0] = ld_stream16(src);
+        pre[1] = ld_stream16(src + THREADS * 16);
+        pre[2] = ld_stream16(src + THREADS * 32);
+        pre[3] = ld_stream16(src + THREADS * 48);
+        if (threadIdx.x < 2) ph = ld_stream16(src - 32);
+    };
+    const uint64_t t_end = tile_first + ntiles;
+    uint64_t t = tile_first + blockIdx.x;
+    issue(t * TB);
+    const uint32_t col4 = kTxt + CT::col(threadIdx.x) * 4u;  // the lane's column; position 32 + x = byte x of its segment
+    // four text bytes from position p of the lane's column (two aligned dwords a row apart + v_alignbyte_b32)
+    auto text4 = [&](uint32_t p) -> uint32_t {
+        const uint32_t at = col4 + (p >> 2) * CT::RS;
+        return __builtin_amdgcn_alignbyte(*(const lds_u32_t*)(size_t)(at + CT::RS), *(const lds_u32_t*)(size_t)at, p);
+    };
+    const uint32_t nrest = w - Q;  // bytes of the window in front of its last gram
+    for (; t < t_end; t += gridDim.x) {
+        const uint64_t tile0 = t * TB;
+        __syncthreads();
+        CT::park(txt, pre, ph);
+        __syncthreads();
+        if (t + gridDim.x < t_end) issue((t + gridDim.x) * TB);
+        uint32_t x0 = 0, x1 = L;  // window ends [x0, x1) of the lane's segment are its own
+        const uint64_t seg = tile0 + (uint64_t)threadIdx.x * L;
+        if (tile0 < e_begin || tile0 + TB > e_end) {  // (uniform) a tile at either end of the range
+            const uint64_t lo = seg > e_begin ? seg : e_begin;
+            const uint64_t hi = seg + L < e_end ? seg + L : e_end;
+            x0 = lo < hi ? (uint32_t)(lo - seg) : 0u;
+            x1 = lo < hi ? (uint32_t)(hi - seg) : 0u;
+        }
+        uint32_t e = 32u + x0;
+        const uint32_t ehi = 32u + x1;
+        uint32_t parked_e = 0;  // LONG: the window end of the tile's first candidate whose 32 bytes matched (0: none; e >= 32)
+        while (e < ehi) {
+            const uint32_t pl = e - (Q - 1);
+            const uint32_t at = col4 + (pl >> 2) * CT::RS;
+            const uint32_t w0 = *(const lds_u32_t*)(size_t)at;
+            const uint32_t w1 = *(const lds_u32_t*)(size_t)(at + CT::RS);
+            const uint32_t x_lo = __builtin_amdgcn_alignbyte(w1, w0, pl);
+            uint32_t g;
+            if (GRAM == 2) {
+                g = __builtin_amdgcn_udot4((x_lo >> cshift) & 0x03030303u, 0x40100401u, 0u, false);
+            } else {
+                const uint32_t w2 = *(const lds_u32_t*)(size_t)(at + 2 * CT::RS);
+                const uint32_t x_hi = __builtin_amdgcn_alignbyte(w2, w1, pl);
+                g = __builtin_amdgcn_udot4((x_lo >> cshift) & 0x01010101u, 0x08040201u, 0u, false) |
+                    (__builtin_amdgcn_udot4((x_hi >> cshift) & 0x01010101u, 0x08040201u, 0u, false) << 4);
+            }
+            const uint32_t ent = *(const lds_u32_t*)(size_t)(4u * g);
+            if (!LONG && nrest == 0) {  // (uniform) the window is one gram
+                hits += ent >> 31;
+            } else if (__any((int32_t)ent < 0)) {  // a candidate somewhere in the wave: one gram in 256 on random text
+                if ((int32_t)ent < 0) {
+                    // the nrest bytes in front of the gram against P[0..nrest), a dword at a time
+                    const uint32_t ws = e - (w - 1);
+                    bool ok = true;
+                    for (uint32_t d = 0; d < nrest; d += 4) {
+                        const uint32_t nb = nrest - d < 4 ? nrest - d : 4u;
+                        const uint32_t mask = nb == 4 ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
+                        ok = ok && ((text4(ws + d) ^ *(const lds_u32_t*)(size_t)(kPat + d)) & mask) == 0;
+                    }
+                    if (ok) {
+                        if (!LONG) ++hits;
+                        else if (parked_e == 0) parked_e = e;
+                        else hits += global_equal(a.text + seg + (e - 32u) + 1, a.blob + w, m - w);  // = text + s + w
+                    }
+                }
+            }
+            e += ent & 0xFFu;
+        }
+        if (LONG && __any(parked_e != 0)) hits += wave_verify(parked_e != 0, a.text + seg + (parked_e - 32u) + 1, a.blob + w, m - w);
+    }
+    flush_hits(hits, a.count, smem);
+}
+
+// ---------------------------------------------------------------------------
 // BNDM with q-grams, 32-bit words like the reference  (src/algos/bndm.c:27-111; reading q bytes of a window at
 // once is bndmq2.c / bndmq4.c:29-72's idea).  w = min(m,32); tiles are indexed by the END of the w-byte (prefix) window.
 // LDS: u32 B[256] (left-aligned: B[c] << (32-w)) | column tile (ColTile)
@@ -27,36 +167,23 @@ namespace sg {
 // 2's loop; English: 2; four symbols: 4; two: 8 — where a loop that reads byte by byte and tests after each walks
 // five to eight dependent LDS round trips deep into nearly every window (rand4 m = 32: 66 %, rand2: 38 %).
 // ---------------------------------------------------------------------------
-// GRAM (round 4) — a TEXT of at most four distinct byte values (TextCodes: what a text consists of is known since it was
-// created).  The Q bytes an iteration reads are then one of 256 grams — Q = 4 symbols of two bits (GRAM = 2), or, on a
-// text of two byte values, Q = 8 symbols of one bit (GRAM = 1) — and the Q mask lookups, shifts and ANDs of the loop
-// above collapse into ONE lookup of G[gram] = AND_i (B[c_i] << i): v_lshrrev, v_and, v_dot4_u32_u8 (the index), the LDS
-// read — 4 vector operations and one LDS read where Q = 4 cost 12 and 4 (Q = 8: 7 and 1 for 24 and 8).  The workgroup
-// derives G from B and the text's codes before it starts (256 entries, Q lookups each).
-// A window that IS one gram (w = Q: 8 bytes on two symbols, 4 on four) needs no state at all: E[gram] holds what BNDM
-// computes for it, occurrence (bit 31) and bndm.c:54's shift `last` (the longest proper suffix of the window that is a
-// prefix of P) — one lookup per window, where the loop above, which forgets what it saw inside a gram, could only move by 1.
-template <int THREADS, int L, bool LONG, int Q, int GRAM = 0>  // LONG: m > 32, prefix hits are verified
+template <int THREADS, int L, bool LONG, int Q, int GRAM = 0>  // LONG: m > 32, prefix hits are verified; GRAM: bndm_gram above
 __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_first,
                                                      uint32_t ntiles, const BatchItem* __restrict__ batch)
 {
-    static_assert(GRAM == 0 || (GRAM == 1 && Q == 8) || (GRAM == 2 && Q == 4), "a gram is 8 one-bit or 4 two-bit symbols");
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if constexpr (GRAM != 0) {
+        bndm_gram<THREADS, L, LONG, Q, GRAM>(a, tile_first, ntiles, smem);
+        return;
+    }
     constexpr int TB = THREADS * L;
     using CT = ColTile<THREADS>;  // a window reaches 31 bytes back: the 32 bytes in front of every segment
     static_assert(L == 64 && (Q == 1 || Q == 2 || Q == 4 || Q == 8), "Q divides 32: no read leaves the window's 32 bytes");
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t m = a.m, w = m < 32 ? m : 32;
     uint32_t* B = reinterpret_cast<uint32_t*>(smem);
-    // GRAM: the table of the grams — G, or E where the window is one gram — takes B's place once it is derived from it
-    // (the loop reads only the one; a kilobyte more per workgroup and the sixth workgroup no longer fits the CU: a
-    // tail round, +10 % — measured)
-    constexpr uint32_t kGt = 0, kEt = 0;
     constexpr uint32_t kTxt = 1024;
     uint8_t* txt = smem + kTxt;
-    // GRAM: the text's codes, from the first words of the text's own allocation (TextCodes, kernels.hpp)
-    const uint32_t cshift = GRAM == 2 ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[0]
-                          : GRAM == 1 ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[2] & 0xFFu : 0u;  // two-bit codes: (c >> shift) & 3; one-bit: (c >> bit) & 1
 
     // masks left-aligned (B'[c] = B[c] << (32-w)): D << 1 then drops factors that can no longer become a prefix, instead
     // of carrying dead bits above bit w-1 as bndm.c's 32-bit word does for m < 32 (the next AND clears them either way:
@@ -66,33 +193,6 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
     if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {  // the walk below addresses LDS by offset
         if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
         return;
-    }
-    if (GRAM) {  // G and E from B and the text's codes: entry g for the gram whose byte i has code (g >> (bits * i)) & (2^bits - 1)
-        __syncthreads();
-        const uint32_t symtab = GRAM == 2 ? reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[1]
-                                          : reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[2] >> 8;  // byte value of each code
-        static_assert(GRAM == 0 || THREADS == 256, "thread g derives entry g, then all overwrite B together");
-        const uint32_t g = threadIdx.x;
-        uint32_t entry;
-        {
-            uint32_t G = 0xFFFFFFFFu, D = 0xFFFFFFFFu, last = w, occ = 0;
-#pragma unroll
-            for (int j = 0; j < Q; ++j) {  // byte Q-1-j of the gram: the j-th byte BNDM reads (right to left)
-                const int i = Q - 1 - j;
-                const uint32_t code = GRAM == 2 ? (g >> (2 * i)) & 3u : (g >> i) & 1u;
-                const uint32_t m_c = B[(symtab >> (8 * code)) & 0xFFu];
-                G &= m_c << i;
-                D &= m_c;                                      // bndm.c:51
-                if ((int32_t)D < 0) {                          // bndm.c:52: the j+1 bytes read are a prefix of P
-                    if ((uint32_t)j + 1 < w) last = w - (j + 1);  // bndm.c:53-54
-                    else occ = 1;                              // bndm.c:55
-                }
-                D <<= 1;                                       // bndm.c:57
-            }
-            entry = (!LONG && w == (uint32_t)Q) ? (occ << 31) | last : G;  // E where the window is one gram, else G
-        }
-        __syncthreads();  // every thread has read B
-        B[g] = entry;
     }
 
     const uint64_t e_begin = a.s_begin + w - 1, e_end = a.s_end + w - 1;
@@ -132,34 +232,6 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
         // m > 32 cells); 2 (LONG, the lanes that saw more than one in this tile — periodic texts) P[32..m) is compared
         // on the spot (bndm.c:99-102).
         uint32_t nocc = 0, last = 0;
-        // the gram the Q bytes in xw are (GRAM): byte i's code in bits [bits * i, bits * (i + 1))
-        auto gram_of = [&](const uint32_t (&xw)[2]) -> uint32_t {
-            if (GRAM == 2) return __builtin_amdgcn_udot4((xw[0] >> cshift) & 0x03030303u, 0x40100401u, 0u, false);
-            const uint32_t lo = __builtin_amdgcn_udot4((xw[0] >> cshift) & 0x01010101u, 0x08040201u, 0u, false);
-            const uint32_t hi = __builtin_amdgcn_udot4((xw[1] >> cshift) & 0x01010101u, 0x08040201u, 0u, false);
-            return lo | (hi << 4);
-        };
-        if (GRAM != 0 && !LONG && w == (uint32_t)Q) {  // (uniform) the window is one gram: a lookup per window, no state
-            uint32_t e = 32u + x0;
-            const uint32_t ehi = 32u + x1;
-            while (e < ehi) {
-                const uint32_t pl = e - (Q - 1);
-                const uint32_t at = col4 + (pl >> 2) * CT::RS;
-                const uint32_t w0 = *(const lds_u32_t*)(size_t)at;
-                const uint32_t w1 = *(const lds_u32_t*)(size_t)(at + CT::RS);
-                uint32_t xw[2];
-                xw[0] = __builtin_amdgcn_alignbyte(w1, w0, pl);
-                xw[1] = 0u;
-                if (Q == 8) {
-                    const uint32_t w2 = *(const lds_u32_t*)(size_t)(at + 2 * CT::RS);
-                    xw[1] = __builtin_amdgcn_alignbyte(w2, w1, pl);
-                }
-                const uint32_t ent = *(const lds_u32_t*)(size_t)(kEt + 4u * gram_of(xw));
-                hits += ent >> 31;
-                e += ent & 0xFFu;
-            }
-            continue;  // next tile
-        }
         auto walk = [&](auto how) {
             constexpr int HOW = decltype(how)::value;
             uint32_t e = 32u + x0, k = 0, D = 0xFFFFFFFFu;
@@ -183,15 +255,11 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
                     }
                 }
                 uint32_t G = 0xFFFFFFFFu;
-                if (GRAM) {
-                    G = *(const lds_u32_t*)(size_t)(kGt + 4u * gram_of(xw));  // the Q masks, shifted and ANDed, ready-made
-                } else {
 #pragma unroll
-                    for (int j = 0; j < Q; ++j) {  // step j reads byte Q-1-j; its mask meets D after Q-1-j more shifts
-                        const int i = Q - 1 - j;
-                        const uint32_t c = (xw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                        G &= *(const lds_u32_t*)(size_t)(4u * c) << i;  // B[c]
-                    }
+                for (int j = 0; j < Q; ++j) {  // step j reads byte Q-1-j; its mask meets D after Q-1-j more shifts
+                    const int i = Q - 1 - j;
+                    const uint32_t c = (xw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                    G &= *(const lds_u32_t*)(size_t)(4u * c) << i;  // B[c]
                 }
                 const uint32_t tt = (D << (Q - 1)) & G;  // bndm.c:51, Q times
                 const uint32_t kq = k + Q;
@@ -244,11 +312,11 @@ hipError_t launch_bndm(const ScanArgs& a, int num_cus, hipStream_t stream, TextC
     while (q > 1 && w % q) q /= 2;
     const bool two_wave = g_tune[2] == 2;
     const int wgs = a.sparse ? 4 : q >= 4 ? 6 : 5;
-    // A text of at most four byte values: the gram table (the kernel's comment).  Eight one-bit symbols per step on two
-    // values, four two-bit symbols on three or four; the window must be whole grams.  tune(1, 9): never (A/B).
-    const int gram = g_tune[1] == 9 ? 0 : ((codes.one & 0xFFu) != 0xFFu && w % 8 == 0) ? 1 : (codes.shift < 7 && w % 4 == 0) ? 2 : 0;
+    // A text of at most four byte values: bndm_gram (the kernel's comment) — eight one-bit symbols per gram on two values
+    // (windows of 8+ bytes), four two-bit symbols on up to four (4+ bytes).  tune(1, 9): never (A/B).
+    const int gram = g_tune[1] == 9 ? 0 : ((codes.one & 0xFFu) != 0xFFu && w >= 8) ? 1 : (codes.shift < 7 && w >= 4) ? 2 : 0;
     if (gram) {
-        const size_t lds = 1024 + ColTile<kBndmT>::bytes();
+        const size_t lds = 1056 + ColTile<kBndmT>::bytes();
         const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
         if (gram == 1) {
             if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, 8, 1>, a, tr, kBndmT, lds, 6, num_cus, stream);

@@ -109,8 +109,8 @@ hipError_t launch_scan_set(int algo, const ScanArgs& first, const BatchItem* dev
 hipError_t launch_find(const ScanArgs& a, unsigned long long* out, unsigned long long cap, int num_cus,
                        hipStream_t stream);
 const char* scan_kernel_name(int algo, uint32_t m, bool prefer_packed, bool so_masks, uint32_t halo = 0);
-// BNDM: bit 8 of the plan's halo (its low byte is bndm_scan's q) — an 8-byte pattern over two symbols: on a text of two byte
-// values its window is ONE gram of bndm_scan<.., GRAM = 1> (a lookup per window, 0.74 of the roofline); bndm_scan at any length
+// BNDM: bit 8 of the plan's halo (its low byte is bndm_scan's q) — a pattern of 8+ bytes over two to four symbols: on a text
+// of at most four byte values bndm_scan<.., GRAM> decides every window with one lookup; bndm_scan at any length
 constexpr uint32_t kBndmGramWindow = 0x100;
 // longest pattern for which a skip algorithm's own LDS-tile loop is slower than an every-byte kernel (0: never)
 uint32_t short_pattern_max_m(int algo);

@@ -309,18 +309,20 @@ def test_kernel_choice_follows_the_pattern(oracle):
             own_four = {"bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs", "hor": "hor_scan" if m >= 32 else "so_runs"}.get(a, "so_runs")
             assert kf(a, eng[200:200 + m]) == own_eng, (a, m)
             assert kf(a, four[:m]) == own_four, (a, m)
-    assert kf("bm", eng[200:207]) == "so_runs" and kf("bm", eng[200:208]) == "bm_scan" and kf("bndm", eng[200:212]) == "so_runs" and kf("bndm", four[:12]) == "so_runs"
+    assert kf("bm", eng[200:207]) == "so_runs" and kf("bm", eng[200:208]) == "bm_scan" and kf("bndm", eng[200:212]) == "so_runs" and kf("bndm", four[:12]) == "bndm_scan"  # (four symbols, 8+ bytes: the gram form)
     assert kf("hor", b"abca") == "so_runs" and kf("bm", four[:4]) == "so_runs" and kf("hor", b"abcd") == "so_runs"
     # two symbols, 16+ bytes: the bit-parallel runs kernel, whatever the algorithm (KMP and KR keep their own, EPSM is
     # the packed matcher except on patterns its first dword cannot tell apart; BNDM its own from 32 bytes on)
     for m in (16, 33, 300):
         for a in engine.ALGOS:
-            want = {"kmp": "kmp_runs", "kr": "hor_scan_bp", "bndm": "bndm_scan" if m >= 32 else "so_runs", "hor": "hor_scan" if m >= 64 else "so_runs"}.get(a, "so_runs")
+            want = {"kmp": "kmp_runs", "kr": "hor_scan_bp", "bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs",
+                    "hor": "hor_scan" if m >= 64 else "so_runs"}.get(a, "so_runs")
             assert kf(a, two[:m]) == want, (a, m)
     assert kf("hor", two[:12]) == "so_runs" and kf("epsm", two[:12]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"
-    # round 4: eight bytes over two symbols are ONE gram of bndm_scan's gram table on a text of two byte values
+    # round 4: 8+ bytes over two to four symbols: bndm_scan's gram form (one lookup per window on a text of <= 4 byte values)
     assert len(set(two[:8].tolist())) == 2 and kf("bndm", two[:8]) == "bndm_scan" and kf("bndml", two[:8]) == "bndm_scan"
-    assert kf("bndm", rnd[:8]) == "so_runs" and kf("bndm", four[:8]) == "so_runs" and kf("sbndm", two[:8]) == "so_runs"
+    assert 3 <= len(set(four[:8].tolist())) <= 4 and kf("bndm", four[:8]) == "bndm_scan" and kf("bndm", four[:9]) == "bndm_scan"
+    assert kf("bndm", rnd[:8]) == "so_runs" and kf("bndm", four[:7]) == "so_runs" and kf("sbndm", two[:8]) == "so_runs"
     # ... and, since so_runs runs at 75-81 %, on four: EPSM from 8 bytes on (the skip algorithms are there by rule 1)
     assert kf("epsm", four[:8]) == "so_runs" and kf("epsm", four[:64]) == "so_runs" and kf("epsm", four[:4]) == "packed_scan"
     eight = oracle.gen_text(9, 8, 0, 5000)

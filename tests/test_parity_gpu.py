@@ -327,8 +327,9 @@ def test_two_symbol_patterns_count_on_shift_or_runs_and_on_their_own_kernels(ora
                     if len(set(P.tolist())) > 2 or not applies(a, m):
                         continue
                     pl = Plan(a, P)
-                    if a == "bndm" or (a == "bndml" and m <= 32):  # round 3: bndm_scan reads 8 bytes of a 32-byte window per step
-                        assert pl.kernel_name == ("bndm_scan" if m >= 32 else "so_runs"), (a, m, pl.kernel_name)
+                    if a == "bndm" or (a == "bndml" and m <= 32):  # round 3: bndm_scan reads 8 bytes of a 32-byte window per step;
+                        # round 4: two symbols, 8+ bytes: its gram form at any length
+                        assert pl.kernel_name == ("bndm_scan" if m >= 32 or len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
                     elif a == "hor":  # round 4: Horspool's q-gram bad-character table (q = 8 on two symbols) from 64 bytes on
                         assert pl.kernel_name == ("hor_scan" if m >= 64 and len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
                     else:
