@@ -316,14 +316,18 @@ hipError_t launch_bndm(const ScanArgs& a, int num_cus, hipStream_t stream, TextC
     // (windows of 8+ bytes), four two-bit symbols on up to four (4+ bytes).  tune(1, 9): never (A/B).
     const int gram = g_tune[1] == 9 ? 0 : ((codes.one & 0xFFu) != 0xFFu && w >= 8) ? 1 : (codes.shift < 7 && w >= 4) ? 2 : 0;
     if (gram) {
+        // workgroups per CU, measured on 1 GiB of sigma 2 / 4 (ms; 6 / 5 / 4 / 3 per CU): m = 8: 0.181 / 0.190 / 0.208 / 0.245;
+        // m = 16: 0.189 / 0.181 / 0.184 / 0.207; m = 32, 256: 0.182 / 0.180 / 0.167 / 0.187 — a window of 32 bytes moves by ~26: a
+        // streaming scan, best with four as the tile kernels on large alphabets are
+        const int gwgs = w >= 32 ? 4 : w >= 16 ? 5 : 6;
         const size_t lds = 1056 + ColTile<kBndmT>::bytes();
         const TileRange tr = tiles_for(a.s_begin + w - 1, a.s_end + w - 1, (uint64_t)kBndmT * kBndmL);
         if (gram == 1) {
-            if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, 8, 1>, a, tr, kBndmT, lds, 6, num_cus, stream);
-            return launch_tiled(bndm_scan<kBndmT, kBndmL, false, 8, 1>, a, tr, kBndmT, lds, 6, num_cus, stream);
+            if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, 8, 1>, a, tr, kBndmT, lds, gwgs, num_cus, stream);
+            return launch_tiled(bndm_scan<kBndmT, kBndmL, false, 8, 1>, a, tr, kBndmT, lds, gwgs, num_cus, stream);
         }
-        if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, 4, 2>, a, tr, kBndmT, lds, 6, num_cus, stream);
-        return launch_tiled(bndm_scan<kBndmT, kBndmL, false, 4, 2>, a, tr, kBndmT, lds, 6, num_cus, stream);
+        if (m > 32) return launch_tiled(bndm_scan<kBndmT, kBndmL, true, 4, 2>, a, tr, kBndmT, lds, gwgs, num_cus, stream);
+        return launch_tiled(bndm_scan<kBndmT, kBndmL, false, 4, 2>, a, tr, kBndmT, lds, gwgs, num_cus, stream);
     }
 #define SG_BNDM(T_, WGS_, Q_)                                                                            \
     do {                                                                                                  \
