@@ -41,7 +41,7 @@ SECTIONS = [
     ("f3 on English, 4 GiB", "sweep_f3_english_4gib"),
 ]
 
-out = ["# Results of session `%s` (%s, 1x MI355X; kernel time by HIP events; % of the 8 TB/s HBM peak)" % (prefix, rnd), "",
+out = ["# Results of session `%s` (%s, 1x MI355X; kernel time by HIP events; %% of the 8 TB/s HBM peak)" % (prefix, rnd), "",
        "Written by `tools/results_md.py %s %s` from `profiles/%s/%s_*` — the raw logs of `tools/gpu_round.sh`, `tools/sweep_all.sh`," % (prefix, rnd, rnd, prefix),
        "`tools/own_sweep.sh` (every cell's counts cross-checked between the kernels).  A mark on a cell says that its plans did not run",
        "on the algorithm's own kernel: **s** = `so_runs`, **p** = `packed_scan`, **~** = only some of the cell's three patterns.", ""]
