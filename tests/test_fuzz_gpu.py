@@ -2,7 +2,8 @@
 
 Seeded and bounded: random texts (sigma 2 .. 256, 1 byte .. 2 MB), pattern sets that are pieces of the text,
 periodic, bordered (u v u), almost periodic or random, planted copies (overlapping, one at the very end), random
-sub-ranges (what a shard sees) — every algorithm through the C ABI, as a pattern set in one call and call by call,
+sub-ranges (what a shard sees), symbols renamed to arbitrary byte values — every algorithm through the C ABI, as a pattern
+set in one call (one grid, or every pattern on its own: smartgpu_search_batch64_each) and call by call,
 on the plan's kernel and on its own (smartgpu_tune(0,1)), against the oracle's brute force (bf.c:25-39).
 400,000 comparisons; tools/fuzz_gpu.py is the open-ended form of the same generator.
 """
@@ -56,6 +57,10 @@ def test_differential_fuzz_every_algorithm_both_routings(oracle):
                 T[k:k + m] = P
         if rng.integers(0, 2):
             T[n - m:] = pats[0]
+        if cases % 3 == 2:       # every third case: the symbols renamed to arbitrary byte values (a text of two, three or four
+            perm = rng.permutation(256).astype(np.uint8)  # values that are not 0..3: the codes of the four-byte and gram tables)
+            T = perm[T]
+            pats = [np.ascontiguousarray(perm[P]) for P in pats]
         text = Text.upload(T)
         ranges = [(0, n)]
         off = int(rng.integers(0, n))
@@ -72,7 +77,7 @@ def test_differential_fuzz_every_algorithm_both_routings(oracle):
                     k = engine.kernel_for(a, pats[0])
                     by_kernel[k] = by_kernel.get(k, 0) + len(pats)
                     if nn >= m:  # the pattern set in one call (smart.c:312-345 as one launch group)
-                        got = smart_amd.search_batch(a, pats, text, off=off, n=nn, per_pattern_times=False)[0].tolist()
+                        got = smart_amd.search_batch(a, pats, text, off=off, n=nn, per_pattern_times=cases % 4 == 0, each=cases % 4 == 0)[0].tolist()
                         assert got == want, ("batch", a, sigma, n, m, off, nn, own, got, want, cases)
                         checks += len(pats)
                     j = int(rng.integers(0, len(pats)))  # and one of them call by call

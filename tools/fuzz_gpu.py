@@ -48,6 +48,10 @@ while time.time() < t_end and not bad:
             T[k:k + m] = P
         if rng.integers(0, 2):
             T[n - m:] = P
+    if rng.integers(0, 3) == 0:  # the symbols renamed to arbitrary byte values (texts of two to four values that are not 0..3)
+        perm = rng.permutation(256).astype(np.uint8)
+        T = perm[T]
+        P = np.ascontiguousarray(perm[P])
     text = Text.upload(T)
     ranges = [(0, n)]
     for _ in range(2):
