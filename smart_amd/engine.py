@@ -30,7 +30,7 @@ class SmartGpuError(RuntimeError):
 
 def build():
     """Compile libsmartgpu.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+    subprocess.check_call(["make", "-s", "-j", str(min(os.cpu_count() or 4, 12)), "-C", os.path.join(_HERE, "csrc")])
 
 
 _loaded = {}
