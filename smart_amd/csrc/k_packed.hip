@@ -28,6 +28,12 @@ struct EpsmFp { uint32_t f0, f1, f2, f3, k0, k1, k2, k3, nd, m; };
 
 // MODE 0: some fingerprint dword is partial (m < 16, m % 4 != 0) -> masked compares;
 // MODE 1: whole dwords only; MODE 2: m > 16, four whole dwords + bytes 16.. verified in memory
+// MODE 3 / 4 (round 4) — a TEXT of at most four distinct byte values (TextCodes): the 32 bytes of a row are packed into
+// 64 bits, two per symbol, and the pattern's first F = min(m, 16) SYMBOLS are compared at the 16 alignments as one masked
+// dword each (v_alignbit_b32, v_xor, v_and, v_cmp) — where the byte-wise modes, on such a text, keep a candidate in
+// every lane through all four fingerprint dwords (0.33-0.44 of the roofline on two symbols).  3: m <= 16; 4: m > 16, bytes
+// 16.. verified in memory.  fp.f0 = the pattern's symbols, fp.k0 = their mask, fp.f1 = the codes' shift, fp.nd = 0 if a
+// pattern byte is no symbol of the text (no occurrence: codes alias)
 // MASK: return the surviving offsets in `pending` instead of counting them (packed_find)
 template <int MODE, bool MASK = false>
 static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const EpsmFp& fp,
@@ -43,6 +49,28 @@ static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const Eps
         const uint32_t lo = lo64 > 16 ? 16u : (uint32_t)lo64;
         const uint32_t hi = hi64 > 16 ? 16u : (uint32_t)hi64;
         cand = (hi > lo && !overlap_lane) ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
+    }
+    if constexpr (MODE >= 3) {
+        auto pack16 = [&](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) -> uint32_t {  // sixteen symbols, the first in bits 0-1
+            const uint32_t c0 = __builtin_amdgcn_udot4((x0 >> fp.f1) & 0x03030303u, 0x40100401u, 0u, false);
+            const uint32_t c1 = __builtin_amdgcn_udot4((x1 >> fp.f1) & 0x03030303u, 0x40100401u, 0u, false);
+            const uint32_t c2 = __builtin_amdgcn_udot4((x2 >> fp.f1) & 0x03030303u, 0x40100401u, 0u, false);
+            const uint32_t c3 = __builtin_amdgcn_udot4((x3 >> fp.f1) & 0x03030303u, 0x40100401u, 0u, false);
+            return c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        };
+        const uint32_t W0 = pack16(d[0], d[1], d[2], d[3]), W1 = pack16(d[4], d[5], d[6], d[7]);
+        uint32_t eq = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t x = k == 0 ? W0 : __builtin_amdgcn_alignbit(W1, W0, 2 * k);
+            eq |= (((x ^ fp.f0) & fp.k0) == 0u) ? (1u << k) : 0u;
+        }
+        cand = fp.nd ? cand & eq : 0u;
+        if (MODE == 4 || MASK) {
+            pending = cand;
+            return 0;
+        }
+        return __popc(cand);
     }
     constexpr bool VERIFY = MODE == 2;
 #define SG_EQ(x, kk, ff) (MODE != 0 ? (SG_W(x) == (ff)) : ((SG_W(x) & (kk)) == (ff)))
@@ -135,6 +163,21 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
     fp.k0 = fpw[4]; fp.k1 = fpw[5]; fp.k2 = fpw[6]; fp.k3 = fpw[7];
     fp.m = a.m;
     fp.nd = (a.m >= 13) ? 4 : (a.m + 3) / 4;  // fingerprint dwords
+    if constexpr (MODE >= 3) {  // the pattern's first F symbols under the TEXT's two-bit codes (the first words of its allocation)
+        const uint32_t* const tc = reinterpret_cast<const uint32_t*>(a.text - kFrontPad);
+        const uint32_t cshift = tc[0], symtab = tc[1];
+        const uint32_t F = a.m < 16 ? a.m : 16u;
+        uint32_t pb = 0, ok = 1;
+        for (uint32_t i = 0; i < F; ++i) {
+            const uint32_t c = a.blob[i], code = (c >> cshift) & 3u;
+            pb |= code << (2u * i);
+            ok &= ((symtab >> (8u * code)) & 0xFFu) == c ? 1u : 0u;  // a byte the text does not hold aliases one it does
+        }
+        fp.f0 = pb;
+        fp.k0 = F == 16 ? 0xFFFFFFFFu : (1u << (2u * F)) - 1u;
+        fp.f1 = cshift;
+        fp.nd = ok;
+    }
 
     uint32_t hits = 0;
     // POLICY 3: a wave-row is 63*16 = 1008 start positions; lane i loads the 16 bytes at
@@ -176,7 +219,7 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
                 hits += epsm_row<MODE>(a, fp, A[j], B[j], (row_first + g + j) * ROW_BYTES + in_row, pend[j],
                                        SHUF && (threadIdx.x & 63u) == 63u);
         }
-        if (MODE == 2) {
+        if (MODE == 2 || MODE == 4) {
             uint32_t any_pend = 0;
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) any_pend |= pend[j];
@@ -257,7 +300,7 @@ __global__ __launch_bounds__(THREADS) void packed_find(ScanArgs a, uint64_t row_
 // algorithms' blobs carry it after their own tables (api.cpp, prepare_scan_args).
 // ---------------------------------------------------------------------------
 template <int ALGO>
-static hipError_t launch_packed_as(const ScanArgs& a, int num_cus, hipStream_t stream)
+static hipError_t launch_packed_as(const ScanArgs& a, int num_cus, hipStream_t stream, TextCodes codes)
 {
     const bool shuf = g_tune[7] == 3;
     const TileRange tr = tiles_for(a.s_begin, a.s_end, shuf ? (uint64_t)(kEpsmT / 64) * 1008 : (uint64_t)kEpsmT * 16);
@@ -282,7 +325,18 @@ static hipError_t launch_packed_as(const ScanArgs& a, int num_cus, hipStream_t s
 #else
 #define SG_PACKED_POLICY(M_) SG_PACKED(M_, 0)
 #endif
-    if (a.m > 16) SG_PACKED_POLICY(2);
+    // EPSM on a text of at most four byte values, 8+ bytes: the symbols packed two bits each (modes 3 / 4); tune(7, 9): never (A/B)
+    bool symbols = false;
+    if constexpr (ALGO == SMARTGPU_EPSM) {
+        symbols = codes.shift < 7 && a.m >= 8 && g_tune[7] == 0;
+        if (symbols) {
+            if (a.m > 16) SG_PACKED(4, 0);
+            else SG_PACKED(3, 0);
+        }
+    }
+    (void)codes;
+    if (symbols) {}
+    else if (a.m > 16) SG_PACKED_POLICY(2);
     else if (a.m % 4 == 0) SG_PACKED_POLICY(1);
     else SG_PACKED_POLICY(0);
 #undef SG_PACKED_POLICY
@@ -290,13 +344,13 @@ static hipError_t launch_packed_as(const ScanArgs& a, int num_cus, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t launch_packed(int kind, const ScanArgs& a, int num_cus, hipStream_t stream)
+hipError_t launch_packed(int kind, const ScanArgs& a, int num_cus, hipStream_t stream, TextCodes codes)
 {
     switch (kind) {
-        case SMARTGPU_HOR: return launch_packed_as<SMARTGPU_HOR>(a, num_cus, stream);
-        case SMARTGPU_BM: return launch_packed_as<SMARTGPU_BM>(a, num_cus, stream);
-        case SMARTGPU_BNDM: return launch_packed_as<SMARTGPU_BNDM>(a, num_cus, stream);
-        case SMARTGPU_EPSM: return launch_packed_as<SMARTGPU_EPSM>(a, num_cus, stream);
+        case SMARTGPU_HOR: return launch_packed_as<SMARTGPU_HOR>(a, num_cus, stream, codes);
+        case SMARTGPU_BM: return launch_packed_as<SMARTGPU_BM>(a, num_cus, stream, codes);
+        case SMARTGPU_BNDM: return launch_packed_as<SMARTGPU_BNDM>(a, num_cus, stream, codes);
+        case SMARTGPU_EPSM: return launch_packed_as<SMARTGPU_EPSM>(a, num_cus, stream, codes);
     }
     return hipErrorInvalidValue;
 }

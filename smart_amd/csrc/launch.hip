@@ -51,7 +51,7 @@ bool tune_supported(int key, int value)
         case 0: return value == 0 || value == 1 || value == 3;  // 2: Horspool on the bank-private tiles
         case 3: return value == 0 || value == 5;                 // superseded KMP kernels (5: kmp_runs without its four-byte table; 6: round 3's one-workgroup form)
         case 6: return value == 0 || value == 5;                 // superseded SO kernels (5: so_runs without the four-symbol table)
-        case 7: return value == 0;                               // packed load policies
+        case 7: return value == 0 || value == 9;                 // packed load policies (9: EPSM without its packed-symbol modes)
         default: return true;
     }
 #endif
@@ -244,7 +244,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
 #endif
             return launch_kmp_runs(a, num_cus, stream, codes);  // per-lane runs streamed through LDS
         }
-        case SMARTGPU_EPSM: return launch_packed(SMARTGPU_EPSM, a, num_cus, stream);  // a.fp_off: prepare_scan_args
+        case SMARTGPU_EPSM: return launch_packed(SMARTGPU_EPSM, a, num_cus, stream, codes);  // a.fp_off: prepare_scan_args
     }
     return hipErrorInvalidValue;
 }

@@ -162,7 +162,7 @@ hipError_t launch_bndml(const ScanArgs& a, int num_cus, hipStream_t stream);
 hipError_t launch_so_runs(const ScanArgs& a, bool shift_and, int num_cus, hipStream_t stream, TextCodes codes);
 hipError_t launch_kmp_runs(const ScanArgs& a, int num_cus, hipStream_t stream, TextCodes codes);
 // k_packed.hip — kind: which algorithm's plan the fingerprint belongs to (SMARTGPU_HOR / _BM / _BNDM / _EPSM: its verification tail)
-hipError_t launch_packed(int kind, const ScanArgs& a, int num_cus, hipStream_t stream);
+hipError_t launch_packed(int kind, const ScanArgs& a, int num_cus, hipStream_t stream, TextCodes codes = TextCodes());
 #ifdef SMARTGPU_AB
 // k_ab.hip — the superseded kernels; *handled = false: the tune settings ask for none of them
 hipError_t launch_ab_so(int algo, const ScanArgs& a, int num_cus, hipStream_t stream, bool* handled);

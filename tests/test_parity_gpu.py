@@ -716,12 +716,25 @@ def test_bndm_gram_tables_on_texts_of_at_most_four_values(oracle):
                 pats = [P, T[77:77 + m].copy(), T[999_999:999_999 + m].copy()]
                 counts, _, _, _ = smart_amd.search_batch("bndm", pats, text)
                 assert counts.tolist() == [oracle.search("bf", p, T) for p in pats], (name, m)
+                # EPSM's packed-symbol modes (8+ bytes on such a text: two bits per symbol, sixteen symbols per compare) and its
+                # byte-wise modes (tune(7,9)) on the same plan
+                assert smart_amd.kernel_for("epsm", P) == "packed_scan"
+                got = smart_amd.search("epsm", P, text)[0]
+                engine.tune(7, 9)
+                plain = smart_amd.search("epsm", P, text)[0]
+                engine.tune(7, 0)
+                assert got == want and plain == want, (name, m, "epsm", got, plain, want)
+                assert smart_amd.search("epsm", P, text, off=54_321, n=1_000_001)[0] == sub_want, (name, m, "epsm")
                 # a symbol the text does not hold: no occurrence, whatever the tables say about codes that are not in use
                 Q = P.copy()
                 Q[m // 2] = 99
-                assert smart_amd.search("bndm", Q, text)[0] == 0, (name, m)
+                assert smart_amd.search("bndm", Q, text)[0] == 0 and smart_amd.search("epsm", Q, text)[0] == 0, (name, m)
+                Q = P.copy()
+                Q[m - 1] = 98   # (beyond the sixteen symbols EPSM compares packed, for the longer patterns)
+                assert smart_amd.search("bndm", Q, text)[0] == 0 and smart_amd.search("epsm", Q, text)[0] == 0, (name, m)
             finally:
                 engine.tune(1, 0)
+                engine.tune(7, 0)
                 engine.tune(0, 0)
             text.free()
     # a fifth value: the text has no codes, the mask loop runs
