@@ -31,7 +31,8 @@ struct EpsmFp { uint32_t f0, f1, f2, f3, k0, k1, k2, k3, nd, m; };
 // MODE 3 / 4 (round 4) — a TEXT of at most four distinct byte values (TextCodes): the 32 bytes of a row are packed into
 // 64 bits, two per symbol, and the pattern's first F = min(m, 16) SYMBOLS are compared at the 16 alignments as one masked
 // dword each (v_alignbit_b32, v_xor, v_and, v_cmp) — where the byte-wise modes, on such a text, keep a candidate in
-// every lane through all four fingerprint dwords (0.33-0.44 of the roofline on two symbols).  3: m <= 16; 4: m > 16, bytes
+// every lane through all four fingerprint dwords (0.31-0.43 of the roofline on two symbols from 16 bytes on; here 0.56-0.58;
+// launched on texts of TWO values only: on four the byte-wise modes are ahead, 0.63-0.67 against 0.55-0.58).  3: m <= 16; 4: m > 16, bytes
 // 16.. verified in memory.  fp.f0 = the pattern's symbols, fp.k0 = their mask, fp.f1 = the codes' shift, fp.nd = 0 if a
 // pattern byte is no symbol of the text (no occurrence: codes alias)
 // MASK: return the surviving offsets in `pending` instead of counting them (packed_find)
@@ -325,10 +326,12 @@ static hipError_t launch_packed_as(const ScanArgs& a, int num_cus, hipStream_t s
 #else
 #define SG_PACKED_POLICY(M_) SG_PACKED(M_, 0)
 #endif
-    // EPSM on a text of at most four byte values, 8+ bytes: the symbols packed two bits each (modes 3 / 4); tune(7, 9): never (A/B)
+    // EPSM on a text of two byte values, 16+ bytes: the symbols packed two bits each (modes 3 / 4); tune(7, 9): never (A/B)
     bool symbols = false;
     if constexpr (ALGO == SMARTGPU_EPSM) {
-        symbols = codes.shift < 7 && a.m >= 8 && g_tune[7] == 0;
+        // measured on 1 GiB, own kernel (ms, symbols / bytes): two values m = 8: 0.229 / 0.209, m = 16: 0.231 / 0.435, 32+: 0.236 / 0.31;
+        // four values: 0.231-0.242 / 0.20-0.213 at every length — the packed symbols pay on two values from 16 bytes on
+        symbols = (codes.one & 0xFFu) != 0xFFu && codes.shift < 7 && a.m >= 16 && g_tune[7] == 0;
         if (symbols) {
             if (a.m > 16) SG_PACKED(4, 0);
             else SG_PACKED(3, 0);
