@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Write profiles/<round>/RESULTS.md — the result tables of one session — from its files in profiles/<round>/<letter>_*:
 
-    python tools/results_md.py j r04
+    python tools/results_md.py p r04 [r]      (r: the session letter of the bench line, if it was re-taken)
 
 (the sweeps of tools/sweep_all.sh and tools/own_sweep.sh rendered by tools/tables.py, the headline from the bench line,
 the PMC ratios from the session's summary).  DESIGN.md points here; nothing in this file is written by hand."""
@@ -12,8 +12,10 @@ import subprocess
 import sys
 
 prefix, rnd = sys.argv[1], sys.argv[2]
+head_prefix = sys.argv[3] if len(sys.argv) > 3 else prefix  # the bench line re-taken after the session's PMC passes were collected
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 root = os.path.join(ROOT, "profiles", rnd, prefix + "_")
+head_root = os.path.join(ROOT, "profiles", rnd, head_prefix + "_")
 
 
 def tab(name):
@@ -46,11 +48,11 @@ out = ["# Results of session `%s` (%s, 1x MI355X; kernel time by HIP events; %% 
        "`tools/own_sweep.sh` (every cell's counts cross-checked between the kernels).  A mark on a cell says that its plans did not run",
        "on the algorithm's own kernel: **s** = `so_runs`, **p** = `packed_scan`, **~** = only some of the cell's three patterns.", ""]
 
-bench = root + "bench_default.json"
+bench = head_root + "bench_default.json"
 if os.path.exists(bench):
     d = json.loads(open(bench).read())
     r = d["roofline"]
-    out += ["## Headline (`bench.py`, %s)" % d["config"]["workload"], "",
+    out += ["## Headline (`bench.py`, %s; `%s_bench_default.json`)" % (d["config"]["workload"], head_prefix), "",
             "* **%.2f TB/s = %.1f %% of 8 TB/s** (= %.0f %% of the measured streaming read, %.0f GB/s); kernel %.4f ms by HIP events over %d launches."
             % (d["value"] / 1000, r["frac"] * 100, r["frac_of_measured_stream_read"] * 100, r["measured_stream_read_GBps"], r["kernel_ms"], d["steps"]),
             "* HBM traffic by PMC: %s" % ("%s B = %.3fx the algorithmic bytes" % ("{:,}".format(r["traffic"]), r["traffic"] / r["bytes_per_launch"]) if r.get("traffic") else "null (%s)" % r.get("traffic_source")),
@@ -58,7 +60,7 @@ if os.path.exists(bench):
             "* `min_frac` (plan's choice): `%s`" % json.dumps(d.get("min_frac")),
             "* `own_kernel_min`: `%s`" % json.dumps(d.get("own_kernel_min")),
             "* `worst_cells`: `%s`" % json.dumps(d.get("worst_cells")), ""]
-    stats = root + "bench_hor_m32_kernel_stats.csv"
+    stats = head_root + "bench_hor_m32_kernel_stats.csv"
     if os.path.exists(stats):
         rows = [x for x in csv.DictReader(open(stats)) if r["kernel"] in x["Name"]]
         if rows:
