@@ -552,6 +552,10 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
             own_holds = m >= 8 && !(distinct <= 8 && 2 * distinct <= m);  // not: a few symbols, each several times
         // ... unless Horspool has its q-gram table for them and a window long enough for its shifts (within 5-10 points of so_runs)
         if (hor_q) own_holds = distinct <= 2 ? m >= 64 : m >= 32;
+        // ... and, round 4, Horspool on GRAMS (k_horg.hip: one exact gram lookup per window on a text of at most four byte values,
+        // 0.7-0.8 of the roofline from 8 bytes on): like BNDM's gram form a bet that the text holds no more byte values than
+        // the pattern (on any other text the launch falls back to the hash table above, or the byte table)
+        if (algo == SMARTGPU_HOR && distinct >= 2 && distinct <= 4 && m >= 8) own_holds = true;
         if (algo == SMARTGPU_BNDM || (algo == SMARTGPU_BNDML && m <= 32)) own_holds = *halo == bndm_q_wanted && (*halo >= 8 ? m >= 32 : m >= 16);  // *halo: bndm_scan's q
         // BNDM over two to four symbols, 8+ bytes: on a text of at most four byte values bndm_scan's GRAM form decides every
         // window with one lookup (k_bndm.hip bndm_gram: 0.74-0.8 of the roofline on rand2 / rand4 at any such length; so_runs

@@ -195,6 +195,13 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
 #ifdef SMARTGPU_AB
             if (regime == 2) return launch_hor_bp(a, num_cus, stream);
 #endif
+            // a TEXT of at most four byte values: Horspool on its grams (k_horg.hip) — eight one-bit symbols from 16 bytes on (two
+            // values), four two-bit symbols from 8; a window shorter than two grams cannot be shifted by more than its own rule
+            // allows (m - Q + 1).  tune(2, 4): never (A/B).  Any other text: the plan's q-gram (hash) table, or the byte table.
+            if (algo == SMARTGPU_HOR && g_tune[2] != 4) {
+                const int gram = ((codes.one & 0xFFu) != 0xFFu && m >= 16) ? 1 : (codes.shift < 7 && m >= 8) ? 2 : 0;
+                if (gram) return launch_hor_gram(a, gram, num_cus, stream);
+            }
             return launch_hor(a, (a_in.halo >> 8) & 0xFFu, num_cus, stream);  // q: the plan's q-gram table (api.cpp), 0: the byte table
         }
         case SMARTGPU_KR:

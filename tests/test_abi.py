@@ -301,12 +301,12 @@ def test_kernel_choice_follows_the_pattern(oracle):
     # natural language, DNA-like alphabets: symbols repeat -> the Shift-Or runs kernel at any m (round 1: packed matcher) —
     # except, since round 3, where the algorithm's own kernel holds on such patterns: the flat loops of bm_scan and
     # hor_scan on natural language from 8 bytes on (not on a few symbols), bndm_scan with q-grams from 16 bytes on (two
-    # symbols: from 32); since round 4 Horspool with its q-gram bad-character table on two to four symbols, from 32 bytes
-    # on (two symbols: from 64)
+    # symbols: from 32); since round 4 Horspool on grams (a text of at most four byte values; on any other text its q-gram
+    # hash table) for patterns over two to four symbols from 8 bytes on, BNDM's gram form likewise
     for m in (16, 64, 1024):
         for a in ("hor", "bm", "bndm", "qs", "raita", "hash3", "sbndm", "bndml", "tunedbm"):
             own_eng = {"bm": "bm_scan", "hor": "hor_scan", "tunedbm": "hor_scan", "bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs"}.get(a, "so_runs")
-            own_four = {"bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs", "hor": "hor_scan" if m >= 32 else "so_runs"}.get(a, "so_runs")
+            own_four = {"bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs", "hor": "hor_scan"}.get(a, "so_runs")  # (round 4: Horspool on grams from 8 bytes on)
             assert kf(a, eng[200:200 + m]) == own_eng, (a, m)
             assert kf(a, four[:m]) == own_four, (a, m)
     assert kf("bm", eng[200:207]) == "so_runs" and kf("bm", eng[200:208]) == "bm_scan" and kf("bndm", eng[200:212]) == "so_runs" and kf("bndm", four[:12]) == "bndm_scan"  # (four symbols, 8+ bytes: the gram form)
@@ -316,9 +316,9 @@ def test_kernel_choice_follows_the_pattern(oracle):
     for m in (16, 33, 300):
         for a in engine.ALGOS:
             want = {"kmp": "kmp_runs", "kr": "hor_scan_bp", "bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs",
-                    "hor": "hor_scan" if m >= 64 else "so_runs"}.get(a, "so_runs")
+                    "hor": "hor_scan"}.get(a, "so_runs")
             assert kf(a, two[:m]) == want, (a, m)
-    assert kf("hor", two[:12]) == "so_runs" and kf("epsm", two[:12]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"
+    assert kf("hor", two[:12]) == "hor_scan" and kf("hor", two[:7]) == "so_runs" and kf("epsm", two[:12]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"
     # round 4: 8+ bytes over two to four symbols: bndm_scan's gram form (one lookup per window on a text of <= 4 byte values)
     assert len(set(two[:8].tolist())) == 2 and kf("bndm", two[:8]) == "bndm_scan" and kf("bndml", two[:8]) == "bndm_scan"
     assert 3 <= len(set(four[:8].tolist())) <= 4 and kf("bndm", four[:8]) == "bndm_scan" and kf("bndm", four[:9]) == "bndm_scan"

@@ -54,7 +54,7 @@ def test_no_product_kernel_uses_scratch():
     1 GiB (so_runs<LONG>): every kernel of the product library must compile without it, and the
     1024-thread runs kernels within the 128 VGPRs their 16 waves per CU allow."""
     usage = resource_usage()
-    scan = {k: v for k, v in usage.items() if re.search(r"(_scan|_runs|_find)I", k)}
+    scan = {k: v for k, v in usage.items() if re.search(r"(_scan|_runs|_find|_gram)I", k)}
     assert len(scan) >= 30, sorted(usage)
     for k, v in scan.items():
         assert v.get("scratch") == 0, (k, v)

@@ -330,8 +330,8 @@ def test_two_symbol_patterns_count_on_shift_or_runs_and_on_their_own_kernels(ora
                     if a == "bndm" or (a == "bndml" and m <= 32):  # round 3: bndm_scan reads 8 bytes of a 32-byte window per step;
                         # round 4: two symbols, 8+ bytes: its gram form at any length
                         assert pl.kernel_name == ("bndm_scan" if m >= 32 or len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
-                    elif a == "hor":  # round 4: Horspool's q-gram bad-character table (q = 8 on two symbols) from 64 bytes on
-                        assert pl.kernel_name == ("hor_scan" if m >= 64 and len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
+                    elif a == "hor":  # round 4: Horspool on grams (two to four symbols, 8+ bytes)
+                        assert pl.kernel_name == ("hor_scan" if len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
                     else:
                         assert (pl.kernel_name == "so_runs") == (a not in own), (a, m, pl.kernel_name)
                     pl.free()
@@ -686,7 +686,7 @@ def test_bndm_gram_tables_on_texts_of_at_most_four_values(oracle):
     alphabets = {"01": [0, 1], "acgt": list(b"ACGT"), "far": [0, 255], "one": [7], "three": [1, 2, 200], "odd": [3, 5]}
     for name, values in alphabets.items():
         vals = np.asarray(values, dtype=np.uint8)
-        for m in (4, 8, 12, 16, 20, 24, 32, 33, 40, 64, 300):
+        for m in (4, 8, 12, 16, 20, 24, 32, 33, 40, 64, 300, 2100, 4200):
             T = vals[oracle.gen_text(991 + m, max(len(values), 2), 0, n) % len(values)]
             P = T[150_000:150_000 + m].copy()
             if m in (8, 24):
@@ -700,7 +700,7 @@ def test_bndm_gram_tables_on_texts_of_at_most_four_values(oracle):
             text = Text.upload(T)
             assert len(text.alphabet()) <= 4
             want = oracle.search("bndm", P, T)
-            assert want >= 100 or name == "one"
+            assert want >= (100 if m <= 300 else 20) or name == "one"  # (long plants overwrite one another)
             sub_want = oracle.search("bf", P, T[54_321:54_321 + 1_000_001])
             engine.tune(0, 1)  # bndm_scan itself at any length
             try:
@@ -712,6 +712,14 @@ def test_bndm_gram_tables_on_texts_of_at_most_four_values(oracle):
                     engine.tune(1, 0)
                     assert got == want and plain == want, (name, m, a, got, plain, want)
                     assert smart_amd.search(a, P, text, off=54_321, n=1_000_001)[0] == sub_want, (name, m, a)
+                # Horspool on grams (k_horg.hip: the bad-character rule on the window's last gram, the table built by the
+                # workgroup from the pattern's last positions) and its byte / hash tables (tune(2,4)) on the same plan
+                got = smart_amd.search("hor", P, text)[0]
+                engine.tune(2, 4)
+                plain = smart_amd.search("hor", P, text)[0]
+                engine.tune(2, 0)
+                assert got == want and plain == want, (name, m, "hor", got, plain, want)
+                assert smart_amd.search("hor", P, text, off=54_321, n=1_000_001)[0] == sub_want, (name, m, "hor")
                 # a pattern set in one grid (texts up to 32 MiB): the grams of every pattern of the set
                 pats = [P, T[77:77 + m].copy(), T[999_999:999_999 + m].copy()]
                 counts, _, _, _ = smart_amd.search_batch("bndm", pats, text)
@@ -728,12 +736,13 @@ def test_bndm_gram_tables_on_texts_of_at_most_four_values(oracle):
                 # a symbol the text does not hold: no occurrence, whatever the tables say about codes that are not in use
                 Q = P.copy()
                 Q[m // 2] = 99
-                assert smart_amd.search("bndm", Q, text)[0] == 0 and smart_amd.search("epsm", Q, text)[0] == 0, (name, m)
+                assert smart_amd.search("bndm", Q, text)[0] == 0 and smart_amd.search("epsm", Q, text)[0] == 0 and smart_amd.search("hor", Q, text)[0] == 0, (name, m)
                 Q = P.copy()
                 Q[m - 1] = 98   # (beyond the sixteen symbols EPSM compares packed, for the longer patterns)
-                assert smart_amd.search("bndm", Q, text)[0] == 0 and smart_amd.search("epsm", Q, text)[0] == 0, (name, m)
+                assert smart_amd.search("bndm", Q, text)[0] == 0 and smart_amd.search("epsm", Q, text)[0] == 0 and smart_amd.search("hor", Q, text)[0] == 0, (name, m)
             finally:
                 engine.tune(1, 0)
+                engine.tune(2, 0)
                 engine.tune(7, 0)
                 engine.tune(0, 0)
             text.free()

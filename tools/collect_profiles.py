@@ -76,7 +76,7 @@ def main():
         best = None
         for r in rows:
             name = r[1].split("sg::", 1)[1].split("<")[0].split("(")[0]
-            if r[0] == algo and r[2] == "FETCH_SIZE" and (name.endswith(("_scan", "_runs", "_scan_bp"))) and (best is None or r[3] > best[1]):
+            if r[0] == algo and r[2] == "FETCH_SIZE" and (name.endswith(("_scan", "_runs", "_scan_bp", "_gram"))) and (best is None or r[3] > best[1]):
                 best = (name, r[3])
         return best[0] if best else None
 
