@@ -24,7 +24,9 @@ namespace sg {
 // the column (m <= 32), else in memory (the first candidate of a tile parked for wave_verify).
 // LDS: u32 E[256] | P[0..32), a flag | column tile
 // ---------------------------------------------------------------------------
-constexpr uint32_t kHorGramScan = 2048;  // pattern positions (from the end) the table is built from
+constexpr uint32_t kHorGramScan = 256;  // pattern positions (from the end) the table is built from: one per thread — a lane owns 64
+                                         // window ends, a shift beyond that moves it out of its segment either way (2048 positions and a
+                                         // byte-wise check of the whole pattern cost a 4096-byte pattern 0.17 ms per GiB in table building)
 
 template <int THREADS, int L, bool LONG, int Q, int GRAM>  // LONG: m > 32 — the window does not lie in the lane's column
 __global__ __launch_bounds__(THREADS) void hor_scan_gram(ScanArgs a1, uint64_t tile_first, uint32_t ntiles, const BatchItem* __restrict__ batch)
@@ -46,7 +48,12 @@ __global__ __launch_bounds__(THREADS) void hor_scan_gram(ScanArgs a1, uint64_t t
     uint32_t* const foreign = reinterpret_cast<uint32_t*>(smem + kPat + 32);  // set if a pattern byte is no symbol of the text
     E[threadIdx.x] = 0;
     if (threadIdx.x == 0) *foreign = 0;
-    if (threadIdx.x < 8) reinterpret_cast<uint32_t*>(smem + kPat)[threadIdx.x] = reinterpret_cast<const uint32_t*>(a.blob)[threadIdx.x];
+    // the pattern bytes in front of its last gram that a candidate is compared with in LDS: all m - Q of them while the window
+    // lies in the column (m <= 32), the 24 nearest otherwise — what is left of a longer window is compared in memory only when
+    // those agree (a candidate in 256 windows is cheap to test in LDS and dear in memory: verifying every one of them there
+    // cost a 4096-byte pattern 0.12 ms per GiB)
+    const uint32_t nlds = LONG ? 24u : m - Q, lds_from = m - Q - nlds;
+    if (threadIdx.x < 32) smem[kPat + threadIdx.x] = threadIdx.x < nlds ? a.blob[lds_from + threadIdx.x] : 0;
     if ((uint32_t)(uintptr_t)(lds_u8_t*)smem != 0u) {  // the walk below addresses LDS by offset
         if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(a.count), 1ull << 62);
         return;
@@ -64,9 +71,17 @@ __global__ __launch_bounds__(THREADS) void hor_scan_gram(ScanArgs a1, uint64_t t
         const uint32_t npos = m - Q, lo = npos > kHorGramScan ? npos - kHorGramScan : 0u;
         for (uint32_t i = lo + threadIdx.x; i < npos; i += THREADS) atomicMax(&E[pgram(i)], i + 1u);
         // a pattern byte that is no symbol of the text cannot occur in it, and its code is some symbol's: no window is a candidate then
-        for (uint32_t i = threadIdx.x; i < m; i += THREADS) {
-            const uint32_t c = a.blob[i];
-            if (((symtab >> (8u * ((c >> cshift) & kMask))) & 0xFFu) != c) atomicOr(foreign, 1u);
+        // (sixteen bytes per thread and step: the pattern slot is 4224 zero-padded bytes; bytes beyond m are not looked at)
+        for (uint32_t i0 = threadIdx.x * 16u; i0 < m; i0 += THREADS * 16u) {
+            const uint4 v = *reinterpret_cast<const uint4*>(a.blob + i0);
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+            uint32_t bad = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint32_t c = (d[q >> 2] >> (8 * (q & 3))) & 0xFFu;
+                bad |= (i0 + q < m && ((symtab >> (8u * ((c >> cshift) & kMask))) & 0xFFu) != c) ? 1u : 0u;
+            }
+            if (bad) atomicOr(foreign, 1u);
         }
         __syncthreads();
         const uint32_t g = threadIdx.x, at = E[g];
@@ -96,7 +111,6 @@ __global__ __launch_bounds__(THREADS) void hor_scan_gram(ScanArgs a1, uint64_t t
         const uint32_t at = col4 + (p >> 2) * CT::RS;
         return __builtin_amdgcn_alignbyte(*(const lds_u32_t*)(size_t)(at + CT::RS), *(const lds_u32_t*)(size_t)at, p);
     };
-    const uint32_t nrest = m - Q;  // bytes of the window in front of its last gram
     for (; t < t_end; t += gridDim.x) {
         const uint64_t tile0 = t * TB;
         __syncthreads();
@@ -132,25 +146,24 @@ __global__ __launch_bounds__(THREADS) void hor_scan_gram(ScanArgs a1, uint64_t t
             const uint32_t ent = *(const lds_u32_t*)(size_t)(4u * g);
             if (__any((int32_t)ent < 0)) {  // the window's last gram is P's somewhere in the wave: hor.c:41-46 for those lanes
                 if ((int32_t)ent < 0) {
-                    if (!LONG) {  // the window lies in the column: its first m - Q bytes against P[0..m-Q), a dword at a time
-                        const uint32_t ws = e - (m - 1);
-                        bool ok = true;
-                        for (uint32_t d = 0; d < nrest; d += 4) {
-                            const uint32_t nb = nrest - d < 4 ? nrest - d : 4u;
-                            const uint32_t mask = nb == 4 ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
-                            ok = ok && ((text4(ws + d) ^ *(const lds_u32_t*)(size_t)(kPat + d)) & mask) == 0;
-                        }
-                        hits += ok;
-                    } else if (parked_e == 0) {
-                        parked_e = e;
-                    } else {  // = text + s: inside the text because the window end is one of the range's
-                        hits += global_equal(a.text + seg + (e - 32u) - (m - 1), a.blob, nrest);
+                    // the nlds bytes in front of the gram against the pattern's, a dword at a time
+                    const uint32_t ws = e - (Q - 1) - nlds;
+                    bool ok = true;
+                    for (uint32_t d = 0; d < nlds; d += 4) {
+                        const uint32_t nb = nlds - d < 4 ? nlds - d : 4u;
+                        const uint32_t mask = nb == 4 ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
+                        ok = ok && ((text4(ws + d) ^ *(const lds_u32_t*)(size_t)(kPat + d)) & mask) == 0;
+                    }
+                    if (ok) {
+                        if (!LONG) ++hits;
+                        else if (parked_e == 0) parked_e = e;
+                        else hits += global_equal(a.text + seg + (e - 32u) - (m - 1), a.blob, lds_from);  // = text + s: the window's first bytes
                     }
                 }
             }
             e += ent & 0x7FFFFFFFu;  // hor.c:49 on grams
         }
-        if (LONG && __any(parked_e != 0)) hits += wave_verify(parked_e != 0, a.text + seg + (parked_e - 32u) - (m - 1), a.blob, nrest);
+        if (LONG && __any(parked_e != 0)) hits += wave_verify(parked_e != 0, a.text + seg + (parked_e - 32u) - (m - 1), a.blob, lds_from);
     }
     flush_hits(hits, a.count, smem);
 }

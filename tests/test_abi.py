@@ -302,7 +302,7 @@ def test_kernel_choice_follows_the_pattern(oracle):
     # except, since round 3, where the algorithm's own kernel holds on such patterns: the flat loops of bm_scan and
     # hor_scan on natural language from 8 bytes on (not on a few symbols), bndm_scan with q-grams from 16 bytes on (two
     # symbols: from 32); since round 4 Horspool on grams (a text of at most four byte values; on any other text its q-gram
-    # hash table) for patterns over two to four symbols from 8 bytes on, BNDM's gram form likewise
+    # hash table) for patterns over two to four symbols from 16 bytes on, BNDM's gram form from 8
     for m in (16, 64, 1024):
         for a in ("hor", "bm", "bndm", "qs", "raita", "hash3", "sbndm", "bndml", "tunedbm"):
             own_eng = {"bm": "bm_scan", "hor": "hor_scan", "tunedbm": "hor_scan", "bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs"}.get(a, "so_runs")
@@ -318,7 +318,7 @@ def test_kernel_choice_follows_the_pattern(oracle):
             want = {"kmp": "kmp_runs", "kr": "hor_scan_bp", "bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs",
                     "hor": "hor_scan"}.get(a, "so_runs")
             assert kf(a, two[:m]) == want, (a, m)
-    assert kf("hor", two[:12]) == "hor_scan" and kf("hor", two[:7]) == "so_runs" and kf("epsm", two[:12]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"
+    assert kf("hor", two[:16]) == "hor_scan" and kf("hor", two[:12]) == "so_runs" and kf("epsm", two[:12]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"
     # round 4: 8+ bytes over two to four symbols: bndm_scan's gram form (one lookup per window on a text of <= 4 byte values)
     assert len(set(two[:8].tolist())) == 2 and kf("bndm", two[:8]) == "bndm_scan" and kf("bndml", two[:8]) == "bndm_scan"
     assert 3 <= len(set(four[:8].tolist())) <= 4 and kf("bndm", four[:8]) == "bndm_scan" and kf("bndm", four[:9]) == "bndm_scan"
