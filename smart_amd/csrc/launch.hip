@@ -221,6 +221,11 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
             // m = 1 always: bm_scan reads the byte before the window's last along with it, and a one-byte
             // window has none (at a tile's first byte that read would leave the tile region)
             if (m == 1 || (m <= packed_max_m(SMARTGPU_BM) && g_tune[0] != 1) || pk) return launch_packed(SMARTGPU_BM, a, num_cus, stream);
+            // a TEXT of at most four byte values: Boyer-Moore on its grams (k_bmg.hip), as Horspool above.  tune(2, 4): never (A/B)
+            if (g_tune[2] != 4) {
+                const int gram = ((codes.one & 0xFFu) != 0xFFu && m >= 16) ? 1 : (codes.shift < 7 && m >= 8) ? 2 : 0;
+                if (gram) return launch_bm_gram(a, gram, num_cus, stream);
+            }
             return launch_bm(a, num_cus, stream);
         case SMARTGPU_BNDML:
             if (m > 32) {  // multi-word vectors; m <= 32 is plain BNDM (bndml.c:44-75): falls through

@@ -154,6 +154,7 @@ hipError_t launch_hor_bp(const ScanArgs& a, int num_cus, hipStream_t stream);   
 #endif
 // k_horg.hip — Horspool on grams (a text of at most four byte values): gram = 1: eight one-bit symbols, 2: four two-bit symbols
 hipError_t launch_hor_gram(const ScanArgs& a, int gram, int num_cus, hipStream_t stream);
+hipError_t launch_bm_gram(const ScanArgs& a, int gram, int num_cus, hipStream_t stream);
 // k_bm.hip
 hipError_t launch_bm(const ScanArgs& a, int num_cus, hipStream_t stream);
 // k_bndm.hip, k_bndmx.hip

@@ -10,7 +10,8 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 COMMON = ("dev_common.hpp", "kernels.hpp", "launch_common.hpp")
 UNITS = {
     "k_hor": ("k_hor.hip",),
-    "k_horg": ("k_horg.hip",),
+    "k_horg": ("k_horg.hip", "gram_skip.hpp"),
+    "k_bmg": ("k_bmg.hip", "gram_skip.hpp"),
     "k_bm": ("k_bm.hip",),
     "k_bndm": ("k_bndm.hip",),
     "k_bndmx": ("k_bndmx.hip",),
@@ -20,7 +21,7 @@ UNITS = {
     "k_util": ("k_util.hip",),
 }
 KERNEL_UNIT = {
-    "hor_scan": "k_hor", "hor_scan_bp": "k_hor", "hor_scan_gram": "k_horg", "bm_scan": "k_bm", "bndm_scan": "k_bndm", "sbndm_scan": "k_bndmx",
+    "hor_scan": "k_hor", "hor_scan_bp": "k_hor", "hor_scan_gram": "k_horg", "bm_scan_gram": "k_bmg", "bm_scan": "k_bm", "bndm_scan": "k_bndm", "sbndm_scan": "k_bndmx",
     "bndml_scan": "k_bndmx", "so_runs": "k_so", "kmp_runs": "k_kmp", "packed_scan": "k_packed", "packed_find": "k_packed",
     "generate_text": "k_util", "tile_fill": "k_util", "text_alphabet": "k_util", "probe_read": "k_util",
 }

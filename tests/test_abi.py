@@ -306,17 +306,17 @@ def test_kernel_choice_follows_the_pattern(oracle):
     for m in (16, 64, 1024):
         for a in ("hor", "bm", "bndm", "qs", "raita", "hash3", "sbndm", "bndml", "tunedbm"):
             own_eng = {"bm": "bm_scan", "hor": "hor_scan", "tunedbm": "hor_scan", "bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs"}.get(a, "so_runs")
-            own_four = {"bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs", "hor": "hor_scan"}.get(a, "so_runs")  # (round 4: Horspool on grams from 8 bytes on)
+            own_four = {"bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs", "hor": "hor_scan", "bm": "bm_scan"}.get(a, "so_runs")  # (round 4: Horspool and Boyer-Moore on grams from 16 bytes on)
             assert kf(a, eng[200:200 + m]) == own_eng, (a, m)
             assert kf(a, four[:m]) == own_four, (a, m)
     assert kf("bm", eng[200:207]) == "so_runs" and kf("bm", eng[200:208]) == "bm_scan" and kf("bndm", eng[200:212]) == "so_runs" and kf("bndm", four[:12]) == "bndm_scan"  # (four symbols, 8+ bytes: the gram form)
     assert kf("hor", b"abca") == "so_runs" and kf("bm", four[:4]) == "so_runs" and kf("hor", b"abcd") == "so_runs"
-    # two symbols, 16+ bytes: the bit-parallel runs kernel, whatever the algorithm (KMP and KR keep their own, EPSM is
+    # two symbols, 16+ bytes: the bit-parallel runs kernel, whatever the algorithm (KMP and KR keep their own, Horspool and Boyer-Moore their gram forms, EPSM is
     # the packed matcher except on patterns its first dword cannot tell apart; BNDM its own from 32 bytes on)
     for m in (16, 33, 300):
         for a in engine.ALGOS:
             want = {"kmp": "kmp_runs", "kr": "hor_scan_bp", "bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs",
-                    "hor": "hor_scan"}.get(a, "so_runs")
+                    "hor": "hor_scan", "bm": "bm_scan"}.get(a, "so_runs")
             assert kf(a, two[:m]) == want, (a, m)
     assert kf("hor", two[:16]) == "hor_scan" and kf("hor", two[:12]) == "so_runs" and kf("epsm", two[:12]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"
     # round 4: 8+ bytes over two to four symbols: bndm_scan's gram form (one lookup per window on a text of <= 4 byte values)

@@ -330,8 +330,8 @@ def test_two_symbol_patterns_count_on_shift_or_runs_and_on_their_own_kernels(ora
                     if a == "bndm" or (a == "bndml" and m <= 32):  # round 3: bndm_scan reads 8 bytes of a 32-byte window per step;
                         # round 4: two symbols, 8+ bytes: its gram form at any length
                         assert pl.kernel_name == ("bndm_scan" if m >= 32 or len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
-                    elif a == "hor":  # round 4: Horspool on grams (two to four symbols, 8+ bytes)
-                        assert pl.kernel_name == ("hor_scan" if len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
+                    elif a in ("hor", "bm"):  # round 4: Horspool and Boyer-Moore on grams (two to four symbols, 16+ bytes)
+                        assert pl.kernel_name == (a + "_scan" if len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
                     else:
                         assert (pl.kernel_name == "so_runs") == (a not in own), (a, m, pl.kernel_name)
                     pl.free()
@@ -714,12 +714,15 @@ def test_bndm_gram_tables_on_texts_of_at_most_four_values(oracle):
                     assert smart_amd.search(a, P, text, off=54_321, n=1_000_001)[0] == sub_want, (name, m, a)
                 # Horspool on grams (k_horg.hip: the bad-character rule on the window's last gram, the table built by the
                 # workgroup from the pattern's last positions) and its byte / hash tables (tune(2,4)) on the same plan
-                got = smart_amd.search("hor", P, text)[0]
-                engine.tune(2, 4)
-                plain = smart_amd.search("hor", P, text)[0]
-                engine.tune(2, 0)
-                assert got == want and plain == want, (name, m, "hor", got, plain, want)
-                assert smart_amd.search("hor", P, text, off=54_321, n=1_000_001)[0] == sub_want, (name, m, "hor")
+                # (and Boyer-Moore on grams, k_bmg.hip: the same loop with the good-suffix shifts joined in; periodic patterns
+                # — m = 8, 24 above — are where bmGs[0] after an occurrence and the shifts of partial matches differ from Horspool's)
+                for a in ("hor", "bm"):
+                    got = smart_amd.search(a, P, text)[0]
+                    engine.tune(2, 4)
+                    plain = smart_amd.search(a, P, text)[0]
+                    engine.tune(2, 0)
+                    assert got == want and plain == want, (name, m, a, got, plain, want)
+                    assert smart_amd.search(a, P, text, off=54_321, n=1_000_001)[0] == sub_want, (name, m, a)
                 # a pattern set in one grid (texts up to 32 MiB): the grams of every pattern of the set
                 pats = [P, T[77:77 + m].copy(), T[999_999:999_999 + m].copy()]
                 counts, _, _, _ = smart_amd.search_batch("bndm", pats, text)
@@ -736,10 +739,10 @@ def test_bndm_gram_tables_on_texts_of_at_most_four_values(oracle):
                 # a symbol the text does not hold: no occurrence, whatever the tables say about codes that are not in use
                 Q = P.copy()
                 Q[m // 2] = 99
-                assert smart_amd.search("bndm", Q, text)[0] == 0 and smart_amd.search("epsm", Q, text)[0] == 0 and smart_amd.search("hor", Q, text)[0] == 0, (name, m)
+                assert smart_amd.search("bndm", Q, text)[0] == 0 and smart_amd.search("epsm", Q, text)[0] == 0 and smart_amd.search("hor", Q, text)[0] == 0 and smart_amd.search("bm", Q, text)[0] == 0, (name, m)
                 Q = P.copy()
                 Q[m - 1] = 98   # (beyond the sixteen symbols EPSM compares packed, for the longer patterns)
-                assert smart_amd.search("bndm", Q, text)[0] == 0 and smart_amd.search("epsm", Q, text)[0] == 0 and smart_amd.search("hor", Q, text)[0] == 0, (name, m)
+                assert smart_amd.search("bndm", Q, text)[0] == 0 and smart_amd.search("epsm", Q, text)[0] == 0 and smart_amd.search("hor", Q, text)[0] == 0 and smart_amd.search("bm", Q, text)[0] == 0, (name, m)
             finally:
                 engine.tune(1, 0)
                 engine.tune(2, 0)

@@ -8,7 +8,7 @@ NAME=$1; shift
 D=$(cd "$(dirname "$0")/../smart_amd/csrc" && pwd)
 T=$(mktemp -d)
 FLAGS="-O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-unused-value"
-for u in k_hor k_horg k_bm k_bndm k_bndmx k_so k_kmp k_packed k_util launch; do
+for u in k_hor k_horg k_bm k_bmg k_bndm k_bndmx k_so k_kmp k_packed k_util launch; do
   /opt/rocm/bin/hipcc $FLAGS "$@" --offload-arch=gfx950 -c -o $T/$u.o $D/$u.hip &
 done
 /opt/rocm/bin/hipcc $FLAGS "$@" --offload-arch=gfx950 -c -o $T/api.o $D/api.cpp &
