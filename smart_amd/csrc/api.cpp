@@ -581,6 +581,9 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
             // 63-68 %); at 75-81 % it also beats the packed matcher on rand4 (EPSM there: 59-67 %, a second
             // fingerprint dword in nearly every row), not on rand8 and up.
             to_so = pass >= 0.03;
+            // EPSM keeps every pattern but the long ones over two symbols: its v_mqsad modes do the same work whatever the text holds
+            // (k_packed.hip: 0.78-0.80 of the roofline on four byte values at any length; two values from 13 bytes on: 0.53-0.56)
+            if (algo == SMARTGPU_EPSM) to_so = distinct <= 2 && m >= 13;
         }
         if (to_so) {
             blob.resize((blob.size() + 15) & ~size_t(15), 0);

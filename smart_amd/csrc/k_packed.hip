@@ -35,6 +35,17 @@ struct EpsmFp { uint32_t f0, f1, f2, f3, k0, k1, k2, k3, nd, m; };
 // launched on texts of TWO values only: on four the byte-wise modes are ahead, 0.63-0.67 against 0.55-0.58).  3: m <= 16; 4: m > 16, bytes
 // 16.. verified in memory.  fp.f0 = the pattern's symbols, fp.k0 = their mask, fp.f1 = the codes' shift, fp.nd = 0 if a
 // pattern byte is no symbol of the text (no occurrence: codes alias)
+// MODES 5-10 (round 4) — epsm.c:165-223's mpsadbw filter with this machine's own instruction: v_mqsad_pk_u16_u8 takes eight
+// text bytes and a four-byte reference and returns the sums of absolute differences at the FOUR byte alignments (16 bits
+// each), skipping reference bytes that are 0, and ADDS them to its third operand.  Four pattern bytes are such a reference
+// (the bytes beyond m are 0); a chain of up to four — the pattern's bytes 4s.. against the text 4s bytes on, accumulated —
+// decides up to sixteen bytes: a sum of 0 is an occurrence.  Text and pattern are XORed with a byte K the pattern does not
+// hold, so no pattern byte is 0.  A quarter-rate instruction (3.5 ordinary VALU slots each: tools/probe valu_rate; its
+// semantics: tools/probe qsad_sem); the sums become flags with v_pk_min_u16(., 1) and are ADDED, two per dword: 16 - sum
+// occurrences — no compare, no select, no ballot, whatever the text holds and however dense the occurrences are.
+//   5 / 6 / 7 / 8: one .. four references, m <= 4 / 8 / 12 / 16, the whole pattern;
+//   9 / 10: the first 16 / 8 bytes, the survivors' other bytes compared in memory (epsm_verify).
+// fp.f0..f3 = the references, fp.k0 = K in every byte.
 // MASK: return the surviving offsets in `pending` instead of counting them (packed_find)
 template <int MODE, bool MASK = false>
 static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const EpsmFp& fp,
@@ -51,7 +62,42 @@ static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const Eps
         const uint32_t hi = hi64 > 16 ? 16u : (uint32_t)hi64;
         cand = (hi > lo && !overlap_lane) ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
     }
-    if constexpr (MODE >= 3) {
+    if constexpr (MODE >= 5) {
+        // references of four pattern bytes: modes 5-8: 1 (m <= 4) .. 4 (m <= 16), the whole pattern; modes 9 / 10: the first 16 / 8 bytes,
+        // the survivors' other bytes compared in memory (epsm_verify)
+        constexpr int NS = MODE == 9 ? 4 : MODE == 10 ? 2 : MODE - 4;
+        constexpr bool SURVIVORS = MODE >= 9;
+        constexpr int NX = 4 + NS;
+        uint32_t x[NX];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) x[j] = d[j] ^ fp.k0;
+        uint32_t nz[8];  // nz[j]: bit 0 / bit 16 = position 2j / 2j + 1 is NO occurrence
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            // the pattern's bytes 4s .. 4s+3 against the text 4s bytes on, ADDED to the sums so far (the accumulator operand)
+            uint64_t r = __builtin_amdgcn_mqsad_pk_u16_u8(((uint64_t)x[g4 + 1] << 32) | x[g4], fp.f0, 0ull);
+            if (NS > 1) r = __builtin_amdgcn_mqsad_pk_u16_u8(((uint64_t)x[g4 + 2] << 32) | x[g4 + 1], fp.f1, r);
+            if (NS > 2) r = __builtin_amdgcn_mqsad_pk_u16_u8(((uint64_t)x[g4 + 3] << 32) | x[g4 + 2], fp.f2, r);
+            if (NS > 3) r = __builtin_amdgcn_mqsad_pk_u16_u8(((uint64_t)x[g4 + 4] << 32) | x[g4 + 3], fp.f3, r);
+            // (as asm: from min(x, 1) on a vector of two the compiler makes two compares, two selects and a v_perm)
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz[2 * g4]) : "v"((uint32_t)r), "v"(0x00010001u));
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz[2 * g4 + 1]) : "v"((uint32_t)(r >> 32)), "v"(0x00010001u));
+        }
+        const uint32_t sum = (nz[0] + nz[1] + nz[2]) + (nz[3] + nz[4] + nz[5]) + (nz[6] + nz[7]);
+        if (!SURVIVORS && !MASK && cand == 0xFFFFu)  // all sixteen positions are the lane's own: every row but the range's first and last
+            return 16u - (sum & 0xFFFFu) - (sum >> 16);
+        if (SURVIVORS && !MASK && !__any(sum != 0x00080008u)) return 0;  // no prefix in the wave's row: the streaming case
+        uint32_t eq = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) eq |= (((nz[j] & 1u) ^ 1u) << (2 * j)) | ((((nz[j] >> 16) & 1u) ^ 1u) << (2 * j + 1));
+        cand &= eq;
+        if (SURVIVORS || MASK) {
+            pending = cand;
+            return 0;
+        }
+        return __popc(cand);
+    }
+    if constexpr (MODE == 3 || MODE == 4) {
         auto pack16 = [&](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) -> uint32_t {  // sixteen symbols, the first in bits 0-1
             const uint32_t c0 = __builtin_amdgcn_udot4((x0 >> fp.f1) & 0x03030303u, 0x40100401u, 0u, false);
             const uint32_t c1 = __builtin_amdgcn_udot4((x1 >> fp.f1) & 0x03030303u, 0x40100401u, 0u, false);
@@ -110,11 +156,11 @@ static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const Eps
 // m > 16: candidates that matched the 16-byte fingerprint.  The lowest candidate of
 // every lane goes to wave_verify, further ones (rare) are checked by the lane itself.
 static __device__ __attribute__((noinline)) uint32_t epsm_verify(const uint8_t* text, const uint8_t* blob,
-                                                                 uint32_t m, uint32_t cand, uint64_t p0)
+                                                                 uint32_t m, uint32_t cand, uint64_t p0, uint32_t from = 16)
 {
     // out of line on purpose: inlined, its control flow pushes the streaming loop of
     // packed_scan over the SGPR budget (spills into the hot path, -12 % measured)
-    const uint32_t len = m - 16;
+    const uint32_t len = m - from;  // bytes from.. (16: the fingerprint's length; mode 10: 8)
     uint32_t c = cand;
     const bool has = c != 0;
     const uint32_t k0 = has ? __builtin_ctz(c) : 0u;
@@ -123,9 +169,9 @@ static __device__ __attribute__((noinline)) uint32_t epsm_verify(const uint8_t* 
     while (c) {
         const uint32_t k = __builtin_ctz(c);
         c &= c - 1;
-        if (!global_equal(text + p0 + k + 16, blob + 16, len)) cand &= ~(1u << k);
+        if (!global_equal(text + p0 + k + from, blob + from, len)) cand &= ~(1u << k);
     }
-    return __popc(cand) + wave_verify(has, text + p0 + k0 + 16, blob + 16, len);
+    return __popc(cand) + wave_verify(has, text + p0 + k0 + from, blob + from, len);
 }
 
 // ALGO only tags the instantiation (rocprofv3 shows packed_scan<256, 4, 5, ..> for
@@ -135,7 +181,7 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
                                                        uint64_t nrows, const BatchItem* __restrict__ batch)
 {
     const ScanArgs a = pick_args(a1, batch);  // a pattern set in one grid: blockIdx.y = pattern (launch_batch)
-    // POLICY 0: A non-temporal, B cached (default); 1: both cached; 3: one nt load + shuffle.
+    // POLICY 0: A non-temporal, B cached (default); 1: both cached; 3: one nt load + shuffle; 5: one nt load + ONE dword by DPP (MODE 5).
     // (Both loads nt measured 62-67 %: the second load must find the line still cached.  A
     // ballot/SGPR formulation of the first-dword test measured 59-73 %: scalar-unit bound.)
     // Also measured and dropped (profiles/r01 session p): completing the few survivors of a dword in
@@ -164,7 +210,25 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
     fp.k0 = fpw[4]; fp.k1 = fpw[5]; fp.k2 = fpw[6]; fp.k3 = fpw[7];
     fp.m = a.m;
     fp.nd = (a.m >= 13) ? 4 : (a.m + 3) / 4;  // fingerprint dwords
-    if constexpr (MODE >= 3) {  // the pattern's first F symbols under the TEXT's two-bit codes (the first words of its allocation)
+    if constexpr (MODE >= 5) {  // the references of v_mqsad: P[0..min(m, 16)) ^ K, K = the smallest byte value those bytes do not hold
+        constexpr uint32_t kF = MODE == 10 ? 8u : 16u;
+        const uint32_t F = a.m < kF ? a.m : kF;
+        uint32_t K = 0;
+        for (uint32_t t = 0; t < 17; ++t) {
+            bool held = false;
+            for (uint32_t i = 0; i < F; ++i) held = held || a.blob[i] == K;
+            if (!held) break;
+            ++K;
+        }
+        uint32_t ref[4] = {0u, 0u, 0u, 0u};
+        for (uint32_t i = 0; i < F; ++i) ref[i >> 2] |= ((uint32_t)a.blob[i] ^ K) << (8u * (i & 3u));
+        fp.f0 = ref[0];
+        fp.f1 = ref[1];
+        fp.f2 = ref[2];
+        fp.f3 = ref[3];
+        fp.k0 = K * 0x01010101u;
+    }
+    if constexpr (MODE == 3 || MODE == 4) {  // the pattern's first F symbols under the TEXT's two-bit codes (the first words of its allocation)
         const uint32_t* const tc = reinterpret_cast<const uint32_t*>(a.text - kFrontPad);
         const uint32_t cshift = tc[0], symtab = tc[1];
         const uint32_t F = a.m < 16 ? a.m : 16u;
@@ -195,12 +259,38 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
         for (int j = 0; j < ROWS; ++j) {
             const uint64_t r = g + j < nrows ? g + j : nrows - 1;  // clamp, ignored below
             const uint8_t* src = a.text + (row_first + r) * ROW_BYTES + in_row;
-            if (SHUF) {
+            if (POLICY == 5) {  // MODE 5 reads 19 bytes per lane: its own sixteen and ONE dword of the next lane's
+                A[j] = ld_stream16(src);
+                B[j] = uint4{0u, 0u, 0u, 0u};
+                if ((threadIdx.x & 63u) == 63u) {  // the wave's last lane has no neighbour
+                    if (MODE == 5) B[j].x = *reinterpret_cast<const uint32_t*>(src + 16);
+                    else if (MODE == 6 || MODE == 10) { const uint2 t2 = *reinterpret_cast<const uint2*>(src + 16); B[j].x = t2.x; B[j].y = t2.y; }
+                    else B[j] = *reinterpret_cast<const uint4*>(src + 16);  // (MODE 7: three dwords would do)
+                }
+            } else if (SHUF) {
                 A[j] = ld_stream16(src);
             } else {
                 // A is this lane's own 16 bytes; B re-reads the next lane's 16 bytes
                 A[j] = NTA ? ld_stream16(src) : *reinterpret_cast<const uint4*>(src);
                 B[j] = NTB ? ld_stream16(src + 16) : *reinterpret_cast<const uint4*>(src + 16);
+            }
+        }
+        if (POLICY == 5) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {  // v_mov_b32_dpp wave_shl:1 — lane i takes lane i + 1's dword, one VALU op, no second load
+                const bool last = (threadIdx.x & 63u) == 63u;
+                const uint32_t next = __builtin_amdgcn_update_dpp(0u, A[j].x, 0x130, 0xF, 0xF, true);
+                B[j].x = last ? B[j].x : next;
+                if (MODE != 5) {
+                    const uint32_t ny = __builtin_amdgcn_update_dpp(0u, A[j].y, 0x130, 0xF, 0xF, true);
+                    B[j].y = last ? B[j].y : ny;
+                }
+                if (MODE != 5 && MODE != 6 && MODE != 10) {
+                    const uint32_t nz = __builtin_amdgcn_update_dpp(0u, A[j].z, 0x130, 0xF, 0xF, true);
+                    const uint32_t nw = __builtin_amdgcn_update_dpp(0u, A[j].w, 0x130, 0xF, 0xF, true);
+                    B[j].z = last ? B[j].z : nz;
+                    B[j].w = last ? B[j].w : nw;
+                }
             }
         }
         if (SHUF) {
@@ -220,7 +310,7 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
                 hits += epsm_row<MODE>(a, fp, A[j], B[j], (row_first + g + j) * ROW_BYTES + in_row, pend[j],
                                        SHUF && (threadIdx.x & 63u) == 63u);
         }
-        if (MODE == 2 || MODE == 4) {
+        if (MODE == 2 || MODE == 4 || MODE >= 9) {
             uint32_t any_pend = 0;
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) any_pend |= pend[j];
@@ -232,7 +322,7 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
                     for (int q = 1; q < ROWS; ++q)
                         if (j == q) c = pend[q];
                     if (__any(c != 0))
-                        hits += epsm_verify(a.text, a.blob, a.m, c, (row_first + g + j) * ROW_BYTES + in_row);
+                        hits += epsm_verify(a.text, a.blob, a.m, c, (row_first + g + j) * ROW_BYTES + in_row, MODE == 10 ? 8u : 16u);
                 }
             }
         }
@@ -316,32 +406,53 @@ static hipError_t launch_packed_as(const ScanArgs& a, int num_cus, hipStream_t s
 #define SG_PACKED(M_, P_)                                                                           \
     hipLaunchKernelGGL((packed_scan<kEpsmT, 4, ALGO, M_, P_>), dim3((uint32_t)grid, g_batch.count), dim3(kEpsmT), 128, \
                        stream, a, tr.first, (uint64_t)tr.count, g_batch.items)
+    // D_: the mode's own data path — 5 (one load, the neighbour's bytes by DPP) except for the masked compares of MODE 0
 #ifdef SMARTGPU_AB  // the other load policies: both loads cached (1), one non-temporal load + shuffle (3)
-#define SG_PACKED_POLICY(M_)                                                 \
+#define SG_PACKED_POLICY(M_, D_)                                             \
     do {                                                                     \
         if (g_tune[7] == 1) SG_PACKED(M_, 1);                                \
         else if (g_tune[7] == 3) SG_PACKED(M_, 3);                           \
-        else SG_PACKED(M_, 0);                                               \
+        else if (g_tune[7] == 7) SG_PACKED(M_, 0);                           \
+        else SG_PACKED(M_, D_);                                              \
     } while (0)
 #else
-#define SG_PACKED_POLICY(M_) SG_PACKED(M_, 0)
+#define SG_PACKED_POLICY(M_, D_)                                             \
+    do {                                                                     \
+        if (g_tune[7] == 7) SG_PACKED(M_, 0);                                \
+        else SG_PACKED(M_, D_);                                              \
+    } while (0)
 #endif
-    // EPSM on a text of two byte values, 16+ bytes: the symbols packed two bits each (modes 3 / 4); tune(7, 9): never (A/B)
+    // v_mqsad_pk_u16_u8 (modes 5-10): the same work whatever the text holds.  Up to 7 bytes always (0.78-0.82 against 0.69-0.76 for
+    // the dword compares on rand128 / English, 0.50 on four symbols); 8+ bytes on a text of at most four byte values, where the
+    // dword compares keep candidates alive through every stage (0.31-0.67); on other texts the dword compares' first stage
+    // decides (8 bytes on rand128: 0.82 against 0.77).  ms per GiB, own kernel, 1 GiB:
+    //   one / two references (m <= 8): 0.166-0.175 on any text;
+    //   three or four values, 9+ bytes: two references — one position in 65536 survives — and the survivors completed in memory
+    //     (mode 10): 0.170-0.173 up to 256 bytes (four references: 0.24-0.25; dword compares 0.21-0.23);
+    //   two values: 9-12 bytes three references 0.19-0.20, 13-15 four 0.23 (dword compares 0.44); 16+: EPSM's packed symbols
+    //     (modes 3 / 4, 0.224-0.233; four references 0.227-0.247; three + survivors — one position in 4096 — 0.25-0.39).
+    // tune(7, 8) / (7, 9): the dword compares; tune(7, 6): references for every byte up to 16; tune(7, 5): the packed symbols only (A/B)
+    const bool few = codes.shift < 7, two = (codes.one & 0xFFu) != 0xFFu;
+    const bool sad = g_tune[7] == 6 || (g_tune[7] == 0 && (a.m <= 7 || few));
     bool symbols = false;
     if constexpr (ALGO == SMARTGPU_EPSM) {
-        // measured on 1 GiB, own kernel (ms, symbols / bytes): two values m = 8: 0.229 / 0.209, m = 16: 0.231 / 0.435, 32+: 0.236 / 0.31;
-        // four values: 0.231-0.242 / 0.20-0.213 at every length — the packed symbols pay on two values from 16 bytes on
-        symbols = (codes.one & 0xFFu) != 0xFFu && codes.shift < 7 && a.m >= 16 && g_tune[7] == 0;
+        symbols = two && few && a.m >= 16 && (g_tune[7] == 0 || g_tune[7] == 5);
         if (symbols) {
             if (a.m > 16) SG_PACKED(4, 0);
             else SG_PACKED(3, 0);
         }
     }
-    (void)codes;
     if (symbols) {}
-    else if (a.m > 16) SG_PACKED_POLICY(2);
-    else if (a.m % 4 == 0) SG_PACKED_POLICY(1);
-    else SG_PACKED_POLICY(0);
+    else if (sad && a.m <= 4) SG_PACKED(5, 5);
+    else if (sad && a.m <= 8) SG_PACKED(6, 5);
+    else if (sad && g_tune[7] != 6 && !two) SG_PACKED(10, 5);
+    else if (sad && a.m <= 12) SG_PACKED(7, 5);
+    else if (sad && a.m <= 16) SG_PACKED(8, 5);
+    else if (sad) SG_PACKED(9, 5);
+    else if (a.m <= 4 && g_tune[7] == 7) SG_PACKED(5, 0);  // (A/B: one stage with the second load)
+    else if (a.m > 16) SG_PACKED_POLICY(2, 5);
+    else if (a.m % 4 == 0) SG_PACKED_POLICY(1, 5);
+    else SG_PACKED_POLICY(0, 0);  // masked compares: more VALU work per position, and the four DPP moves + selects cost it 2-3 points (measured)
 #undef SG_PACKED_POLICY
 #undef SG_PACKED
     return hipGetLastError();

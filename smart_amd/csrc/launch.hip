@@ -51,7 +51,7 @@ bool tune_supported(int key, int value)
         case 0: return value == 0 || value == 1 || value == 3;  // 2: Horspool on the bank-private tiles
         case 3: return value == 0 || value == 5;                 // superseded KMP kernels (5: kmp_runs without its four-byte table; 6: round 3's one-workgroup form)
         case 6: return value == 0 || value == 5;                 // superseded SO kernels (5: so_runs without the four-symbol table)
-        case 7: return value == 0 || value == 9;                 // packed load policies (9: EPSM without its packed-symbol modes)
+        case 7: return value == 0 || (value >= 5 && value <= 9);   // packed load policies (9: EPSM without its packed-symbol modes; 8: m <= 4 without v_mqsad)
         default: return true;
     }
 #endif

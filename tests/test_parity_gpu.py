@@ -149,6 +149,45 @@ def test_packed_load_policies(oracle, ab_library, policy):
         engine.tune(7, 0)
 
 
+def test_packed_matcher_sums_of_absolute_differences(oracle):
+    """packed_scan's v_mqsad_pk_u16_u8 modes (k_packed.hip, modes 5-9: epsm.c:165-223's mpsadbw filter on this machine) against
+    its dword compares (tune(7,9)) and the oracle: every length 1..20 and some beyond, on two, four, 128 and 256 byte values;
+    patterns that hold the byte values 0, 1, 2, ... (the XOR byte K must dodge them: a reference byte of 0 is skipped by the
+    instruction); dense and planted occurrences; sub-ranges whose first and last rows are partial; tune(7,6) = these modes
+    on every text and at every length."""
+    from smart_amd import engine
+    rng = np.random.default_rng(77)
+    n = 2_000_003
+    for sigma in (2, 4, 128, 256):
+        T = oracle.gen_text(4242 + sigma, sigma, 0, n)
+        if sigma == 256:
+            T[100_000:100_040] = np.arange(40, dtype=np.uint8)  # a stretch 0, 1, 2, ...: patterns cut from it hold every small value
+        text = Text.upload(T)
+        for m in list(range(1, 21)) + [33, 100, 1000]:
+            cuts = [T[777:777 + m].copy(), T[n - m:].copy()]
+            if sigma == 256:
+                cuts.append(T[100_000:100_000 + min(m, 40)].copy())
+            for P in cuts:
+                for k in rng.integers(0, n - len(P), 50):
+                    T[k:k + len(P)] = P
+            text.free()
+            text = Text.upload(T)
+            for P in cuts:
+                want = oracle.search("bf", P, T)
+                sub = oracle.search("bf", P, T[1_234_567 - 1:1_234_567 - 1 + 500_001])
+                got = {}
+                for t in (0, 6, 9):
+                    engine.tune(7, t)
+                    try:
+                        got[t] = (smart_amd.search("epsm", P, text)[0], smart_amd.search("epsm", P, text, off=1_234_566, n=500_001)[0])
+                    finally:
+                        engine.tune(7, 0)
+                assert all(v == (want, sub) for v in got.values()), (sigma, len(P), got, want, sub)
+                if len(P) <= 7:  # the short patterns of the skip algorithms take the same road
+                    assert smart_amd.search("hor", P, text)[0] == want and smart_amd.search("bndm", P, text)[0] == want, (sigma, len(P))
+        text.free()
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_alternate_serial_kernels(oracle, ab_library, variant):
     """SO and KMP normally run on the bank-private / full-table runs kernels; the variants kept
@@ -725,16 +764,21 @@ def test_bndm_gram_tables_on_texts_of_at_most_four_values(oracle):
                     assert smart_amd.search(a, P, text, off=54_321, n=1_000_001)[0] == sub_want, (name, m, a)
                 # a pattern set in one grid (texts up to 32 MiB): the grams of every pattern of the set
                 pats = [P, T[77:77 + m].copy(), T[999_999:999_999 + m].copy()]
-                counts, _, _, _ = smart_amd.search_batch("bndm", pats, text)
-                assert counts.tolist() == [oracle.search("bf", p, T) for p in pats], (name, m)
-                # EPSM's packed-symbol modes (8+ bytes on such a text: two bits per symbol, sixteen symbols per compare) and its
-                # byte-wise modes (tune(7,9)) on the same plan
+                pats_want = [oracle.search("bf", p, T) for p in pats]
+                for a in ("bndm", "hor", "bm"):
+                    counts, _, _, _ = smart_amd.search_batch(a, pats, text)
+                    assert counts.tolist() == pats_want, (name, m, a)
+                # EPSM on such a text: v_mqsad_pk_u16_u8 at every length (modes 5-9: one to four references of four bytes, the rest
+                # of a long pattern verified), its dword compares (tune(7,9)) and the packed-symbol modes of two-value texts
+                # (tune(7,5)) on the same plan; tune(7,6): the v_mqsad modes on any text
                 assert smart_amd.kernel_for("epsm", P) == "packed_scan"
                 got = smart_amd.search("epsm", P, text)[0]
-                engine.tune(7, 9)
-                plain = smart_amd.search("epsm", P, text)[0]
+                others = []
+                for t in (9, 5, 6):
+                    engine.tune(7, t)
+                    others.append(smart_amd.search("epsm", P, text)[0])
                 engine.tune(7, 0)
-                assert got == want and plain == want, (name, m, "epsm", got, plain, want)
+                assert got == want and others == [want] * 3, (name, m, "epsm", got, others, want)
                 assert smart_amd.search("epsm", P, text, off=54_321, n=1_000_001)[0] == sub_want, (name, m, "epsm")
                 # a symbol the text does not hold: no occurrence, whatever the tables say about codes that are not in use
                 Q = P.copy()
