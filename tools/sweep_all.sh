@@ -11,9 +11,9 @@ run() { name=$1; shift; echo "== $name"; timeout -k 10 500 python tools/sweep.py
 run sweep_rand128_full --ms $MS_FULL --reps 3 &&
 run sweep_rand128_own --ms 4,8,16,32,64,256 --reps 3 --own &&
 run sweep_rand4 --sigma 4 --ms 2,4,8,16,32,64 --reps 3 &&
-run sweep_rand4_own --sigma 4 --ms 2,4,8,16,32,64 --reps 3 --own --algos hor,bm,bndm &&
+run sweep_rand4_own --sigma 4 --ms 2,4,8,16,32,64 --reps 3 --own --algos hor,bm,bndm,epsm &&
 run sweep_rand2 --sigma 2 --ms 2,4,8,16,32,64 --reps 3 &&
-run sweep_rand2_own --sigma 2 --ms 2,4,8,16,32,64 --reps 3 --own --algos hor,bm,bndm &&
+run sweep_rand2_own --sigma 2 --ms 2,4,8,16,32,64 --reps 3 --own --algos hor,bm,bndm,epsm &&
 run sweep_english_4gib --corpus english --gib 4 --ms $MS_FULL --reps 3 &&
 run sweep_english_4gib_own --corpus english --gib 4 --ms 2,4,8,16,32,64,256,1024,4096 --reps 3 --own --algos hor,bm,bndm &&
 run sweep_cfg5_rand2_4gib --sigma 2 --gib 4 --ms $MS_FULL --algos hor,bm,kmp,so,epsm --reps 3 &&
