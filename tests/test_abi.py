@@ -311,15 +311,15 @@ def test_kernel_choice_follows_the_pattern(oracle):
             assert kf(a, four[:m]) == own_four, (a, m)
     assert kf("bm", eng[200:207]) == "so_runs" and kf("bm", eng[200:208]) == "bm_scan" and kf("bndm", eng[200:212]) == "so_runs" and kf("bndm", four[:12]) == "bndm_scan"  # (four symbols, 8+ bytes: the gram form)
     assert kf("hor", b"abca") == "so_runs" and kf("bm", four[:4]) == "so_runs" and kf("hor", b"abcd") == "so_runs"
-    # two symbols, 16+ bytes: the bit-parallel runs kernel, whatever the algorithm (KMP and KR keep their own, Horspool and Boyer-Moore their gram forms, EPSM is
+    # two symbols, 16+ bytes: the bit-parallel runs kernel, whatever the algorithm (KMP and KR keep their own, Horspool and Boyer-Moore their gram forms from 32 bytes on, EPSM is
     # the packed matcher except on patterns its first dword cannot tell apart; BNDM its own from 32 bytes on)
     for m in (16, 33, 300):
         for a in engine.ALGOS:
             want = {"kmp": "kmp_runs", "kr": "hor_scan_bp", "bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs",
-                    "hor": "hor_scan", "bm": "bm_scan"}.get(a, "so_runs")
+                    "hor": "hor_scan" if m >= 32 else "so_runs", "bm": "bm_scan" if m >= 32 else "so_runs"}.get(a, "so_runs")
             assert kf(a, two[:m]) == want, (a, m)
     # (EPSM, round 4: its v_mqsad references decide up to 12 bytes on two symbols at the runs kernel's pace: it keeps those)
-    assert kf("hor", two[:16]) == "hor_scan" and kf("hor", two[:12]) == "so_runs" and kf("epsm", two[:12]) == "packed_scan" and kf("epsm", two[:13]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"
+    assert kf("hor", two[:32]) == "hor_scan" and kf("bm", two[:32]) == "bm_scan" and kf("hor", two[:31]) == "so_runs" and kf("hor", four[:16]) == "hor_scan" and kf("hor", four[:15]) == "so_runs" and kf("epsm", two[:12]) == "packed_scan" and kf("epsm", two[:13]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"
     # round 4: 8+ bytes over two to four symbols: bndm_scan's gram form (one lookup per window on a text of <= 4 byte values)
     assert len(set(two[:8].tolist())) == 2 and kf("bndm", two[:8]) == "bndm_scan" and kf("bndml", two[:8]) == "bndm_scan"
     assert 3 <= len(set(four[:8].tolist())) <= 4 and kf("bndm", four[:8]) == "bndm_scan" and kf("bndm", four[:9]) == "bndm_scan"

@@ -369,8 +369,8 @@ def test_two_symbol_patterns_count_on_shift_or_runs_and_on_their_own_kernels(ora
                     if a == "bndm" or (a == "bndml" and m <= 32):  # round 3: bndm_scan reads 8 bytes of a 32-byte window per step;
                         # round 4: two symbols, 8+ bytes: its gram form at any length
                         assert pl.kernel_name == ("bndm_scan" if m >= 32 or len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
-                    elif a in ("hor", "bm"):  # round 4: Horspool and Boyer-Moore on grams (two to four symbols, 16+ bytes)
-                        assert pl.kernel_name == (a + "_scan" if len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
+                    elif a in ("hor", "bm"):  # round 4: Horspool and Boyer-Moore on grams (two symbols: 32+ bytes)
+                        assert pl.kernel_name == (a + "_scan" if len(set(P.tolist())) == 2 and m >= 32 else "so_runs"), (a, m, pl.kernel_name)
                     else:
                         assert (pl.kernel_name == "so_runs") == (a not in own), (a, m, pl.kernel_name)
                     pl.free()
