@@ -583,7 +583,7 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
             // fingerprint dword in nearly every row), not on rand8 and up.
             to_so = pass >= 0.03;
             // EPSM keeps every pattern but the long ones over two symbols: its v_mqsad modes do the same work whatever the text holds
-            // (k_packed.hip: 0.78-0.80 of the roofline on four byte values at any length; two values from 13 bytes on: 0.53-0.56)
+            // (k_packed.hip: 0.78-0.80 of the roofline on four byte values at any length; two values from 13 bytes on: 0.70-0.74, so_runs 0.77)
             if (algo == SMARTGPU_EPSM) to_so = distinct <= 2 && m >= 13;
         }
         if (to_so) {

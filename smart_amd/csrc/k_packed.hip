@@ -20,7 +20,7 @@ namespace sg {
 // ROWS rows (ROWS * 4 KiB per workgroup) are loaded before any is processed so
 // that enough bytes are in flight per CU to cover HBM latency.
 // ---------------------------------------------------------------------------
-struct EpsmFp { uint32_t f0, f1, f2, f3, k0, k1, k2, k3, nd, m; };
+struct EpsmFp { uint32_t f0, f1, f2, f3, k0, k1, k2, k3, nd, m; uint32_t q[16]; };  // q: modes 3 / 4
 
 // text dword at byte offset x (compile-time after unrolling) of the 8-dword window d[]
 #define SG_W(x) (((x) & 3) == 0 ? d[(x) >> 2] \
@@ -28,13 +28,16 @@ struct EpsmFp { uint32_t f0, f1, f2, f3, k0, k1, k2, k3, nd, m; };
 
 // MODE 0: some fingerprint dword is partial (m < 16, m % 4 != 0) -> masked compares;
 // MODE 1: whole dwords only; MODE 2: m > 16, four whole dwords + bytes 16.. verified in memory
-// MODE 3 / 4 (round 4) — a TEXT of at most four distinct byte values (TextCodes): the 32 bytes of a row are packed into
-// 64 bits, two per symbol, and the pattern's first F = min(m, 16) SYMBOLS are compared at the 16 alignments as one masked
-// dword each (v_alignbit_b32, v_xor, v_and, v_cmp) — where the byte-wise modes, on such a text, keep a candidate in
-// every lane through all four fingerprint dwords (0.31-0.43 of the roofline on two symbols from 16 bytes on; here 0.56-0.58;
-// launched on texts of TWO values only: on four the byte-wise modes are ahead, 0.63-0.67 against 0.55-0.58).  3: m <= 16; 4: m > 16, bytes
-// 16.. verified in memory.  fp.f0 = the pattern's symbols, fp.k0 = their mask, fp.f1 = the codes' shift, fp.nd = 0 if a
-// pattern byte is no symbol of the text (no occurrence: codes alias)
+// MODE 3 / 4 (round 4) — a TEXT of TWO byte values (TextCodes.one: the bit that tells them apart), POLICY 6: a lane packs its
+// own sixteen bytes into sixteen BITS (per dword: shift, and, one v_dot4 with the weights 1, 2, 4, 8) and takes the next lane's
+// sixteen by ONE v_mov_b32_dpp wave_shl:1 (rows of 63 x 16 positions: the wave's last lane only supplies its bits).  The match
+// vector of the sixteen alignments is computed bit-sliced over the PATTERN: M &= (W >> j) ^ (P[j] ? 0 : ~0) for j < F =
+// min(m, 16) — a shift and one v_bitop3 per pattern symbol for all sixteen positions at once, (21 + 2 F) / 16 VALU ops per
+// position where the byte-wise modes keep a candidate in every lane through all four fingerprint dwords (0.31-0.43 of the
+// roofline from 16 bytes on).  3: m <= 16, exact; 4: m > 16, bytes 16.. of the survivors (one position in 65536) verified in
+// memory.  fp.f0 = the pattern's F bits, fp.f1 = the text's bit, fp.k0 = F, fp.nd = 0 if a pattern byte is no symbol of the
+// text (no occurrence: codes alias).  Own kernel, 1 GiB of two values: 9 … 4096 bytes 0.181-0.19 ms = 0.70-0.74 of the roofline
+// (before: two bits per symbol, sixteen symbols per compare at each alignment: 0.56-0.58; four v_mqsad references: 0.55-0.58).
 // MODES 5-10 (round 4) — epsm.c:165-223's mpsadbw filter with this machine's own instruction: v_mqsad_pk_u16_u8 takes eight
 // text bytes and a four-byte reference and returns the sums of absolute differences at the FOUR byte alignments (16 bits
 // each), skipping reference bytes that are 0, and ADDS them to its third operand.  Four pattern bytes are such a reference
@@ -98,21 +101,19 @@ static __device__ __forceinline__ uint32_t epsm_row(const ScanArgs& a, const Eps
         return __popc(cand);
     }
     if constexpr (MODE == 3 || MODE == 4) {
-        auto pack16 = [&](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) -> uint32_t {  // sixteen symbols, the first in bits 0-1
-            const uint32_t c0 = __builtin_amdgcn_udot4((x0 >> fp.f1) & 0x03030303u, 0x40100401u, 0u, false);
-            const uint32_t c1 = __builtin_amdgcn_udot4((x1 >> fp.f1) & 0x03030303u, 0x40100401u, 0u, false);
-            const uint32_t c2 = __builtin_amdgcn_udot4((x2 >> fp.f1) & 0x03030303u, 0x40100401u, 0u, false);
-            const uint32_t c3 = __builtin_amdgcn_udot4((x3 >> fp.f1) & 0x03030303u, 0x40100401u, 0u, false);
-            return c0 | (c1 << 8) | (c2 << 16) | (c3 << 24);
+        auto nib = [&](uint32_t x) -> uint32_t {  // four bytes -> four bits, the first in bit 0
+            return __builtin_amdgcn_udot4((x >> fp.f1) & 0x01010101u, 0x08040201u, 0u, false);
         };
-        const uint32_t W0 = pack16(d[0], d[1], d[2], d[3]), W1 = pack16(d[4], d[5], d[6], d[7]);
-        uint32_t eq = 0;
+        const uint32_t w16 = nib(d[0]) | (nib(d[1]) << 4) | (nib(d[2]) << 8) | (nib(d[3]) << 12);
+        const uint32_t W = w16 | (__builtin_amdgcn_update_dpp(0u, w16, 0x130, 0xF, 0xF, true) << 16);  // the next lane's sixteen bits above the lane's own
+        // fp.q[j]: pattern symbol 1: 0 — the text's bits themselves; 0: ~0 — their complement (sixteen scalars, set once per kernel:
+        // computed inside this loop they cost 4.5 scalar ops per symbol and the scalar unit, shared by the CU, bound the kernel)
+        uint32_t M = fp.nd ? cand : 0u;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const uint32_t x = k == 0 ? W0 : __builtin_amdgcn_alignbit(W1, W0, 2 * k);
-            eq |= (((x ^ fp.f0) & fp.k0) == 0u) ? (1u << k) : 0u;
+        for (int j = 0; j < 16; ++j) {
+            if (MODE == 4 || (uint32_t)j < fp.k0) M &= (W >> j) ^ fp.q[j];  // (mode 4: F = 16; mode 3: a uniform test per symbol)
         }
-        cand = fp.nd ? cand & eq : 0u;
+        cand = M & 0xFFFFu;
         if (MODE == 4 || MASK) {
             pending = cand;
             return 0;
@@ -228,20 +229,22 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
         fp.f3 = ref[3];
         fp.k0 = K * 0x01010101u;
     }
-    if constexpr (MODE == 3 || MODE == 4) {  // the pattern's first F symbols under the TEXT's two-bit codes (the first words of its allocation)
-        const uint32_t* const tc = reinterpret_cast<const uint32_t*>(a.text - kFrontPad);
-        const uint32_t cshift = tc[0], symtab = tc[1];
+    if constexpr (MODE == 3 || MODE == 4) {  // the pattern's first F symbols as bits, under the TEXT's one-bit code (the first words of its allocation)
+        const uint32_t one = reinterpret_cast<const uint32_t*>(a.text - kFrontPad)[2];
+        const uint32_t bit = one & 0xFFu, s0 = (one >> 8) & 0xFFu, s1 = (one >> 16) & 0xFFu;
         const uint32_t F = a.m < 16 ? a.m : 16u;
         uint32_t pb = 0, ok = 1;
         for (uint32_t i = 0; i < F; ++i) {
-            const uint32_t c = a.blob[i], code = (c >> cshift) & 3u;
-            pb |= code << (2u * i);
-            ok &= ((symtab >> (8u * code)) & 0xFFu) == c ? 1u : 0u;  // a byte the text does not hold aliases one it does
+            const uint32_t c = a.blob[i], code = (c >> bit) & 1u;
+            pb |= code << i;
+            ok &= (code ? s1 : s0) == c ? 1u : 0u;  // a byte the text does not hold aliases one it does
         }
         fp.f0 = pb;
-        fp.k0 = F == 16 ? 0xFFFFFFFFu : (1u << (2u * F)) - 1u;
-        fp.f1 = cshift;
+        fp.f1 = bit;
+        fp.k0 = F;
         fp.nd = ok;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) fp.q[j] = 0u - ((~pb >> j) & 1u);
     }
 
     uint32_t hits = 0;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
     // row + 16*i ONCE (non-temporal) and takes the next 16 bytes from lane i+1 by a
     // cross-lane shuffle; lane 63 only supplies the overlap into the next wave-row.
     // Other policies: a row is THREADS*16 offsets and every lane loads 32 bytes.
-    constexpr bool SHUF = POLICY == 3;
+    constexpr bool SHUF = POLICY == 3 || POLICY == 6;  // 6: modes 3 / 4 (the neighbour's BITS travel, inside epsm_row)
     constexpr uint32_t ROW_BYTES = SHUF ? (THREADS / 64) * 1008u : THREADS * 16u;
     const uint32_t in_row = SHUF ? (threadIdx.x >> 6) * 1008u + (threadIdx.x & 63u) * 16u : threadIdx.x * 16u;
     // a workgroup takes ROWS consecutive rows per step
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
                 }
             } else if (SHUF) {
                 A[j] = ld_stream16(src);
+                if (POLICY == 6) B[j] = uint4{0u, 0u, 0u, 0u};
             } else {
                 // A is this lane's own 16 bytes; B re-reads the next lane's 16 bytes
                 A[j] = NTA ? ld_stream16(src) : *reinterpret_cast<const uint4*>(src);
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
                 }
             }
         }
-        if (SHUF) {
+        if (POLICY == 3) {
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) {
                 B[j].x = __shfl_down(A[j].x, 1, 64);
@@ -393,7 +397,9 @@ __global__ __launch_bounds__(THREADS) void packed_find(ScanArgs a, uint64_t row_
 template <int ALGO>
 static hipError_t launch_packed_as(const ScanArgs& a, int num_cus, hipStream_t stream, TextCodes codes)
 {
-    const bool shuf = g_tune[7] == 3;
+    const bool two_l = (codes.one & 0xFFu) != 0xFFu && codes.shift < 7;
+    const bool bits = ALGO == SMARTGPU_EPSM && two_l && a.m >= 9 && (g_tune[7] == 0 || g_tune[7] == 5);  // modes 3 / 4 (below)
+    const bool shuf = g_tune[7] == 3 || bits;
     const TileRange tr = tiles_for(a.s_begin, a.s_end, shuf ? (uint64_t)(kEpsmT / 64) * 1008 : (uint64_t)kEpsmT * 16);
     if (tr.count == 0) return hipSuccess;
     const int rows = 4;  // rows in flight per workgroup step (1 and 2 measured slower, profiles/r01)
@@ -429,17 +435,16 @@ static hipError_t launch_packed_as(const ScanArgs& a, int num_cus, hipStream_t s
     //   one / two references (m <= 8): 0.166-0.175 on any text;
     //   three or four values, 9+ bytes: two references — one position in 65536 survives — and the survivors completed in memory
     //     (mode 10): 0.170-0.173 up to 256 bytes (four references: 0.24-0.25; dword compares 0.21-0.23);
-    //   two values: 9-12 bytes three references 0.19-0.20, 13-15 four 0.23 (dword compares 0.44); 16+: EPSM's packed symbols
-    //     (modes 3 / 4, 0.224-0.233; four references 0.227-0.247; three + survivors — one position in 4096 — 0.25-0.39).
-    // tune(7, 8) / (7, 9): the dword compares; tune(7, 6): references for every byte up to 16; tune(7, 5): the packed symbols only (A/B)
+    //   two values, 9+ bytes: EPSM's bit-sliced modes 3 / 4: 0.181-0.19 (three references 0.19-0.20, four 0.23-0.24; three +
+    //     survivors — one position in 4096 — 0.25-0.39; dword compares 0.32-0.44).
+    // tune(7, 8) / (7, 9): the dword compares; tune(7, 6): references for every byte up to 16 (A/B)
     const bool few = codes.shift < 7, two = (codes.one & 0xFFu) != 0xFFu;
     const bool sad = g_tune[7] == 6 || (g_tune[7] == 0 && (a.m <= 7 || few));
-    bool symbols = false;
+    const bool symbols = bits;
     if constexpr (ALGO == SMARTGPU_EPSM) {
-        symbols = two && few && a.m >= 16 && (g_tune[7] == 0 || g_tune[7] == 5);
         if (symbols) {
-            if (a.m > 16) SG_PACKED(4, 0);
-            else SG_PACKED(3, 0);
+            if (a.m > 16) SG_PACKED(4, 6);
+            else SG_PACKED(3, 6);
         }
     }
     if (symbols) {}
