@@ -559,7 +559,7 @@ void build_blob(std::vector<uint8_t>& blob, int algo, const uint8_t* P, uint32_t
         // 0.37 / 0.63 — a window of one or two grams: those stay with so_runs)
         // (Boyer-Moore likewise, k_bmg.hip: its good-suffix rule joined with the gram's shift)
         // (two symbols, 16 bytes — a window of two grams —: 0.66-0.69 against so_runs' 0.77: those from 32 bytes on, 0.78-0.81)
-        if ((algo == SMARTGPU_HOR || algo == SMARTGPU_BM) && distinct >= 2 && distinct <= 4) own_holds = m >= (distinct <= 2 ? 32u : 16u);
+        if ((algo == SMARTGPU_HOR || algo == SMARTGPU_BM || algo == SMARTGPU_TUNEDBM) && distinct >= 2 && distinct <= 4) own_holds = m >= (distinct <= 2 ? 32u : 16u);
         if (algo == SMARTGPU_BNDM || (algo == SMARTGPU_BNDML && m <= 32)) own_holds = *halo == bndm_q_wanted && (*halo >= 8 ? m >= 32 : m >= 16);  // *halo: bndm_scan's q
         // BNDM over two to four symbols, 8+ bytes: on a text of at most four byte values bndm_scan's GRAM form decides every
         // window with one lookup (k_bndm.hip bndm_gram: 0.74-0.8 of the roofline on rand2 / rand4 at any such length; so_runs

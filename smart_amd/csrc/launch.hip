@@ -198,7 +198,7 @@ hipError_t launch_scan(int algo, const ScanArgs& a_in, int num_cus, hipStream_t 
             // a TEXT of at most four byte values: Horspool on its grams (k_horg.hip) — eight one-bit symbols from 16 bytes on (two
             // values), four two-bit symbols from 8; a window shorter than two grams cannot be shifted by more than its own rule
             // allows (m - Q + 1).  tune(2, 4): never (A/B).  Any other text: the plan's q-gram (hash) table, or the byte table.
-            if (algo == SMARTGPU_HOR && g_tune[2] != 4) {
+            if (g_tune[2] != 4) {  // (Tuned BM — tunedbm.c:38-62 — is Horspool's shift behind an unrolled skip loop: on grams the same kernel)
                 const int gram = ((codes.one & 0xFFu) != 0xFFu && m >= 16) ? 1 : (codes.shift < 7 && m >= 8) ? 2 : 0;
                 if (gram) return launch_hor_gram(a, gram, num_cus, stream);
             }

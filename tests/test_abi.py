@@ -306,7 +306,7 @@ def test_kernel_choice_follows_the_pattern(oracle):
     for m in (16, 64, 1024):
         for a in ("hor", "bm", "bndm", "qs", "raita", "hash3", "sbndm", "bndml", "tunedbm"):
             own_eng = {"bm": "bm_scan", "hor": "hor_scan", "tunedbm": "hor_scan", "bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs"}.get(a, "so_runs")
-            own_four = {"bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs", "hor": "hor_scan", "bm": "bm_scan"}.get(a, "so_runs")  # (round 4: Horspool and Boyer-Moore on grams from 16 bytes on)
+            own_four = {"bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs", "hor": "hor_scan", "tunedbm": "hor_scan", "bm": "bm_scan"}.get(a, "so_runs")  # (round 4: Horspool, Tuned BM and Boyer-Moore on grams from 16 bytes on)
             assert kf(a, eng[200:200 + m]) == own_eng, (a, m)
             assert kf(a, four[:m]) == own_four, (a, m)
     assert kf("bm", eng[200:207]) == "so_runs" and kf("bm", eng[200:208]) == "bm_scan" and kf("bndm", eng[200:212]) == "so_runs" and kf("bndm", four[:12]) == "bndm_scan"  # (four symbols, 8+ bytes: the gram form)
@@ -316,7 +316,7 @@ def test_kernel_choice_follows_the_pattern(oracle):
     for m in (16, 33, 300):
         for a in engine.ALGOS:
             want = {"kmp": "kmp_runs", "kr": "hor_scan_bp", "bndm": "bndm_scan", "bndml": "bndm_scan" if m <= 32 else "so_runs",
-                    "hor": "hor_scan" if m >= 32 else "so_runs", "bm": "bm_scan" if m >= 32 else "so_runs"}.get(a, "so_runs")
+                    "hor": "hor_scan" if m >= 32 else "so_runs", "tunedbm": "hor_scan" if m >= 32 else "so_runs", "bm": "bm_scan" if m >= 32 else "so_runs"}.get(a, "so_runs")
             assert kf(a, two[:m]) == want, (a, m)
     # (EPSM, round 4: its v_mqsad references decide up to 12 bytes on two symbols at the runs kernel's pace: it keeps those)
     assert kf("hor", two[:32]) == "hor_scan" and kf("bm", two[:32]) == "bm_scan" and kf("hor", two[:31]) == "so_runs" and kf("hor", four[:16]) == "hor_scan" and kf("hor", four[:15]) == "so_runs" and kf("epsm", two[:12]) == "packed_scan" and kf("epsm", two[:13]) == "so_runs" and kf("epsm", two[:7]) == "packed_scan"

@@ -369,8 +369,8 @@ def test_two_symbol_patterns_count_on_shift_or_runs_and_on_their_own_kernels(ora
                     if a == "bndm" or (a == "bndml" and m <= 32):  # round 3: bndm_scan reads 8 bytes of a 32-byte window per step;
                         # round 4: two symbols, 8+ bytes: its gram form at any length
                         assert pl.kernel_name == ("bndm_scan" if m >= 32 or len(set(P.tolist())) == 2 else "so_runs"), (a, m, pl.kernel_name)
-                    elif a in ("hor", "bm"):  # round 4: Horspool and Boyer-Moore on grams (two symbols: 32+ bytes)
-                        assert pl.kernel_name == (a + "_scan" if len(set(P.tolist())) == 2 and m >= 32 else "so_runs"), (a, m, pl.kernel_name)
+                    elif a in ("hor", "bm", "tunedbm"):  # round 4: Horspool, Tuned BM and Boyer-Moore on grams (two symbols: 32+ bytes)
+                        assert pl.kernel_name == (("bm_scan" if a == "bm" else "hor_scan") if len(set(P.tolist())) == 2 and m >= 32 else "so_runs"), (a, m, pl.kernel_name)
                     else:
                         assert (pl.kernel_name == "so_runs") == (a not in own), (a, m, pl.kernel_name)
                     pl.free()
@@ -755,7 +755,7 @@ def test_bndm_gram_tables_on_texts_of_at_most_four_values(oracle):
                 # workgroup from the pattern's last positions) and its byte / hash tables (tune(2,4)) on the same plan
                 # (and Boyer-Moore on grams, k_bmg.hip: the same loop with the good-suffix shifts joined in; periodic patterns
                 # — m = 8, 24 above — are where bmGs[0] after an occurrence and the shifts of partial matches differ from Horspool's)
-                for a in ("hor", "bm"):
+                for a in ("hor", "bm", "tunedbm"):
                     got = smart_amd.search(a, P, text)[0]
                     engine.tune(2, 4)
                     plain = smart_amd.search(a, P, text)[0]
