@@ -248,19 +248,26 @@ int smartgpu_probe_read_ms(const smartgpu_text *t, int reps, double *ms_per_pass
  *      the packed matcher, patterns of 16+ bytes over two or three symbols on so_runs, the rest on
  *      the algorithm's own LDS-tile skip loop / 1 always the algorithm's own skip
  *      loop / 2 Horspool's bank-private LDS layout / 3 always the packed matcher
- *   1  bndm_scan: bytes of a window read per iteration (1, 2, 4, 8; 0 = the plan's choice from the pattern)
+ *   1  bndm_scan: bytes of a window read per iteration (1, 2, 4, 8; 0 = the plan's choice from the pattern);
+ *      9 = the plan's choice and never the gram form of texts of at most four byte values (round 4)
  *   2  bm_scan / bndm_scan workgroups: 1 four waves / 2 two waves (0 = default: bm_scan two where the pattern's symbols
  *      repeat, bndm_scan always four); 3 = Horspool's nested loop also where the pattern's symbols repeat (default
- *      there: its flat form, round 3)
+ *      there: its flat form, round 3); 4 = Horspool, Tuned BM and Boyer-Moore never on grams (round 4: hor_scan_gram,
+ *      bm_scan_gram on texts of at most four byte values)
  *   4  workgroups per CU of the LDS-tile kernels (0 = the launcher's choice)
  *   3  KMP: 0 kmp_runs (transition table) / 1 kmp_scan (LDS tiles, m <= 40) / 2 kmp_links_runs
  *      (failure links followed per byte) / 5 kmp_runs a byte per table step even on a text of at most four
- *      byte values (round 3: there it takes four)
+ *      byte values (round 3: there it takes four) / 6 round 3's one-workgroup-per-CU form (round 4: five compact
+ *      workgroups per CU; key 4 sets their number)
  *   5  run length in bytes of the runs kernels (so_runs, kmp_runs); 0 = default
  *   6  SO: 0 so_runs (bank-private table, line fetch) / 1 so_scan (LDS tiles) / 2 so_runs64
  *      (shared table, 64-byte steps); SA: 3 = its own AND form (default: the complemented, Shift-Or form);
  *      5 so_runs a byte per table lookup even on a text of at most four byte values (round 3: there it takes four)
- *   7  packed matcher load policy: 0 A non-temporal + B cached / 1 both cached / 3 one load + shuffle */
+ *   7  packed matcher: 0 default — v_mqsad_pk_u16_u8 references for m <= 7 and on texts of at most four byte values,
+ *      dword compares otherwise, the neighbour lane's bytes by DPP (round 4) / 1 both loads cached / 3 one load +
+ *      shuffle / 6 v_mqsad references at every length / 7 the second (cached) load instead of DPP / 8, 9 dword
+ *      compares only
+ * Settings whose kernels exist only in the A/B build (libsmartgpu_ab.so) are refused by the product library. */
 int smartgpu_tune(int key, int value);
 
 /* Host-side preprocessing exposed for tests (same tables the kernels stage in
