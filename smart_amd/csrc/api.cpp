@@ -195,6 +195,8 @@ smartgpu_text* text_alloc(uint64_t n, int device, DeviceCtx** ctx_out)
 // texts on one device cannot interleave their passes.
 constexpr size_t kAlphabetScratchOff = 64;
 static_assert(kAlphabetScratchOff + 32 <= sg::kFrontPad - (SMARTGPU_XSIZE + 256), "the scratch must lie below every byte a scan can read");
+static_assert(sg::kHitSlotsOff >= kAlphabetScratchOff + 32 && sg::kHitSlotsOff + sg::kHitSlots * 128 <= sg::kFrontPad - (SMARTGPU_XSIZE + 256),
+              "flush_hits' staging slots lie between the scratch and the bytes a scan can read");
 bool text_alphabet(smartgpu_text* t, DeviceCtx* d)
 {
     uint32_t* dev = reinterpret_cast<uint32_t*>(t->base + kAlphabetScratchOff);

@@ -105,7 +105,14 @@ __device__ __forceinline__ void stage_tile(uint8_t* __restrict__ lds,
 // same result slot serialise behind each other at the end of the kernel.)  `lds` is any 8-byte
 // aligned 128 bytes of the kernel's LDS: every wave is past its last use of the LDS when it gets
 // here, which the first barrier establishes for the whole workgroup.
-__device__ __forceinline__ void flush_hits(uint32_t lane_hits, unsigned long long* out, void* lds)
+// Round 4: a grid of a thousand workgroups and more that ALL have occurrences still ends in that many atomics on one
+// address — 72 us behind a 0.67 ms scan of 4 GiB with packed_scan's 4096 workgroups (tools/hits_probe2.py: 44 us with
+// 2048, nothing with 1024).  Such grids (one pattern per grid) add their sums to 64 staging slots first — 128 bytes apart
+// in the text's own front pad (kHitSlotsOff: zero when a kernel starts, zero again when it ends; searches of one text
+// are serialised on its device's stream) —, workgroup b to slot b % 64 together with a 1 in the slot's top 16 bits; the
+// workgroup that finds all the others of its slot there adds the slot's sum to the result and clears it: 64 addresses with
+// gridDim.x / 64 atomics each, then at most 64 on the result.
+__device__ __forceinline__ void flush_hits(uint32_t lane_hits, unsigned long long* out, void* lds, const uint8_t* text)
 {
     unsigned long long v = lane_hits;
 #pragma unroll
@@ -117,7 +124,19 @@ __device__ __forceinline__ void flush_hits(uint32_t lane_hits, unsigned long lon
     if (threadIdx.x == 0) {
         unsigned long long sum = 0;
         for (uint32_t w = 0; w < blockDim.x / 64; ++w) sum += part[w];
-        if (sum != 0) atomicAdd(out, sum);
+        if (gridDim.y > 1 || gridDim.x < kHitSlotsMinGrid) {
+            if (sum != 0) atomicAdd(out, sum);
+        } else {
+            const uint32_t g = blockIdx.x % kHitSlots;
+            const uint32_t members = (gridDim.x - g + kHitSlots - 1) / kHitSlots;  // workgroups b = g (mod 64) of this grid
+            unsigned long long* slot = reinterpret_cast<unsigned long long*>(const_cast<uint8_t*>(text) - kFrontPad + kHitSlotsOff) + 16u * g;
+            const unsigned long long old = atomicAdd(slot, sum + (1ull << 48));   // (a sum stays below 2^48: at most one occurrence per text byte)
+            if ((old >> 48) + 1 == members) {
+                const unsigned long long total = (old + sum) & ((1ull << 48) - 1);
+                atomicExch(slot, 0ull);
+                if (total != 0) atomicAdd(out, total);
+            }
+        }
     }
 }
 

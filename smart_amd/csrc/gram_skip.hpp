@@ -215,7 +215,7 @@ __device__ __forceinline__ void gram_skip_scan(const ScanArgs& a, uint64_t tile_
         }
         if (LONG && __any(parked_e != 0)) hits += wave_verify(parked_e != 0, a.text + seg + (parked_e - 32u) - (m - 1), a.blob, lds_from);
     }
-    flush_hits(hits, a.count, smem);
+    flush_hits(hits, a.count, smem, a.text);
 }
 
 

@@ -142,7 +142,7 @@ __device__ __forceinline__ void bndm_gram(const ScanArgs& a, uint64_t tile_first
         }
         if (LONG && __any(parked_e != 0)) hits += wave_verify(parked_e != 0, a.text + seg + (parked_e - 32u) + 1, a.blob + w, m - w);
     }
-    flush_hits(hits, a.count, smem);
+    flush_hits(hits, a.count, smem, a.text);
 }
 
 // ---------------------------------------------------------------------------
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(THREADS) void bndm_scan(ScanArgs a1, uint64_t tile_
             }
         }
     }
-    flush_hits(hits, a.count, smem);
+    flush_hits(hits, a.count, smem, a.text);
 }
 
 

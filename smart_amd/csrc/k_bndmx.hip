@@ -104,7 +104,7 @@ __global__ __launch_bounds__(THREADS) void sbndm_scan(ScanArgs a1, uint64_t tile
         }
         if (LONG) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
     }
-    flush_hits(hits, a.count, smem);
+    flush_hits(hits, a.count, smem, a.text);
 }
 
 // ---------------------------------------------------------------------------
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(THREADS) void bndml_scan(ScanArgs a1, uint64_t tile
         }
         if (LONG) hits += wave_verify(parked, parked_at, a.blob + w, m - w);
     }
-    flush_hits(hits, a.count, smem);
+    flush_hits(hits, a.count, smem, a.text);
 }
 
 

@@ -125,7 +125,7 @@ __device__ __forceinline__ void hor_flat(const ScanArgs& a, uint64_t tile_first,
             }
         }
     }
-    flush_hits(hits, a.count, smem);
+    flush_hits(hits, a.count, smem, a.text);
 }
 
 template <int THREADS, int L, bool LONG, int VAR>  // LONG: m-1 > back halo, windows are completed in HBM
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(THREADS) void hor_scan(ScanArgs a1, uint64_t tile_f
         }
         if (LONG) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
-    flush_hits(hits, a.count, smem);
+    flush_hits(hits, a.count, smem, a.text);
 }
 
 // ---------------------------------------------------------------------------
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kBpThreads) void hor_scan_bp(ScanArgs a1, uint64_t 
         }
         if (KR && m - 1 > H) hits += wave_verify(parked, parked_at, a.blob, m - 1 - H);
     }
-    flush_hits(hits, a.count, smem);
+    flush_hits(hits, a.count, smem, a.text);
 }
 
 

@@ -401,7 +401,7 @@ void kmp_runs(ScanArgs a1, uint32_t run_len, uint64_t nruns, uint32_t dfa_off, c
         }
     }
     if (COMPACT && !PREFIX) hits >>= 2;  // the counting walk's |next - min(next, 4w)| is 4 per occurrence with Z = 4w + 4
-    flush_hits(hits, a.count, smem);
+    flush_hits(hits, a.count, smem, a.text);
 }
 
 // ---------------------------------------------------------------------------

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(THREADS) void packed_scan(ScanArgs a1, uint64_t row
             }
         }
     }
-    flush_hits(hits, a.count, smem);
+    flush_hits(hits, a.count, smem, a.text);
 }
 
 // Occurrence POSITIONS (an extension: the reference only counts, define.h:33).  The packed

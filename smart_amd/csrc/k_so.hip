@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void so_runs(ScanArgs a1, uint32_t 
             half(k * kRunLine + 64u);
         }
     }
-    flush_hits(hits, a.count, smem);
+    flush_hits(hits, a.count, smem, a.text);
 }
 
 // ---------------------------------------------------------------------------

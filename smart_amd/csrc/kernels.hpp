@@ -13,7 +13,13 @@ namespace sg {
 // pads zero-filled.  Text byte 0 is 256-byte aligned.  The pads let every tile
 // load (a tile plus its halo, rounded to 16 B) stay inside the allocation with
 // no per-load bounds checks; pad bytes are never counted as text.
-constexpr uint64_t kFrontPad = 4608;            // >= kXSize + 256, multiple of 256
+constexpr uint64_t kFrontPad = 4608 + 8704;     // >= kHitSlotsOff + 8 KB of staging slots + kXSize + 256, multiple of 256
+constexpr uint32_t kHitSlots = 64;              // flush_hits (dev_common.hpp): staging slots for the workgroups' sums, 128 bytes apart,
+constexpr uint32_t kHitSlotsOff = 512;          // at this offset of the text's allocation (below every byte a scan reads, above the alphabet scratch)
+#ifndef SMARTGPU_HIT_SLOTS_MIN_GRID
+#define SMARTGPU_HIT_SLOTS_MIN_GRID 1024
+#endif
+constexpr uint32_t kHitSlotsMinGrid = SMARTGPU_HIT_SLOTS_MIN_GRID;  // grids of fewer workgroups add to the result directly (variant builds: A/B)
 constexpr uint64_t kBackPad = 160 * 1024;       // >= largest tile + kXSize + 64
 constexpr uint32_t kBmHalo = 20;                // bm_scan's lane tiles: 16 bytes of the previous segment + 4 of padding per lane
 constexpr uint32_t kHaloMax = 16;               // bytes a lane verifies by itself in LDS before it parks the window
