@@ -32,7 +32,7 @@ build / the CPU oracle for the cpu_baseline sample.  A mismatch aborts the run.
 At N = 1 a per-cell sweep follows: every cell of BASELINE config 2
 (HOR/BM/KMP/SO/BNDM/EPSM x m in {4,8,32,256} on the 1 GiB rand128 text), of
 config 3 (SO, BNDM x sigma in {2,4} x m in {2..64} on 1 GiB) and of configs 4 and
-5 at 1 GiB, each timed with HIP events (the median of 4 rounds of 3 patterns), with the kernel that
+5 at the 4 GiB BASELINE.json states per GPU, each timed with HIP events (the median of 4 rounds of 3 patterns), with the kernel that
 ran, its fraction of the 8 TB/s HBM peak and a count check; cells whose plans
 were rerouted to another kernel are measured again on the algorithm's own kernel
 (smartgpu_tune(0,1)).  The CELLS go to a file (--sweep-out, default
@@ -57,6 +57,7 @@ sys.path.insert(0, ROOT)
 SEED = 0x5EED0001        # corpus seed
 PATTERN_SALT = 0x0A77E2  # k_j = splitmix64(PATTERN_SALT + 4096*j + m) mod (n-m)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BIG_GIB = 4.0            # run_sweep: the text of BASELINE configs 4 and 5 per GPU (4 GiB English; one of eight 4 GiB shards)
 OWN_KERNEL = {"hor": "hor_scan", "bm": "bm_scan", "kmp": "kmp_runs", "so": "so_runs", "bndm": "bndm_scan",
               "epsm": "packed_scan"}
 
@@ -530,9 +531,10 @@ def worst_cells_summary(cells, k=3):
 
 def run_sweep(text128, device):
     """Cells of BASELINE config 2 (six algorithms x m in {4,8,32,256}, 1 GiB rand128), config 3
-    (SO and BNDM x sigma in {2,4} x m in {2,4,8,16,32,64}, 1 GiB), config 4's corpus (the English
-    unit bible.txt||world192.txt tiled to 1 GiB here, six algorithms x the lengths of sets.h:25) and
-    config 5's alphabets (sigma in {2,32,256} x HOR/BM/KMP/SO/EPSM x sets.h:25, one 1 GiB shard):
+    (SO and BNDM x sigma in {2,4} x m in {2,4,8,16,32,64}, 1 GiB), config 4 (the English unit
+    bible.txt||world192.txt tiled to its stated 4 GiB, six algorithms x the lengths of sets.h:25) and
+    config 5's alphabets (sigma in {2,32,256} x HOR/BM/KMP/SO/EPSM x sets.h:25, the 4 GiB shard one of its
+    eight GPUs holds — round 4: these two ran on 1 GiB texts before; BIG_GIB below):
     the harness loop of src/smart.c:290-345 reduced to what it times: per cell 4 rounds of 3 patterns,
     each round between two HIP events on the launch stream; a cell's time is its median round.  Every cell names the kernel its plans
     launched; a cell whose plans were rerouted (api.cpp build_blob) is measured again on the
@@ -542,12 +544,13 @@ def run_sweep(text128, device):
     from smart_amd import Plan, Text, engine
 
     n = 1 << 30
+    BIG = int(BIG_GIB * (1 << 30))  # configs 4 and 5: the size BASELINE.json states per GPU
     J, REPS = 3, 4
     cells = []
     ref_counts = {}
     checked_by = collections.Counter()
 
-    def time_cell(config, text, sigma, algo, m, pats, own):
+    def time_cell(config, text, sigma, algo, m, pats, own, n):
         if own:
             engine.tune(0, 1)
         try:
@@ -580,7 +583,7 @@ def run_sweep(text128, device):
                 try:
                     fam = next((f for f in ("epsm", "kmp", "so") if engine.kernel_for(f, p) != pl.kernel_name), None)
                     if fam is not None:
-                        key = (sigma, m, j, fam, tuned)
+                        key = (sigma, n, m, j, fam, tuned)
                         if key not in ref_counts:
                             ref_counts[key] = smart_amd.search(fam, p, text)[0]
                         checked_by[engine.kernel_for(fam, p)] += 1
@@ -593,7 +596,7 @@ def run_sweep(text128, device):
         for pl in plans:
             pl.free()
         kernel = kernels.most_common(1)[0][0]
-        cell = {"config": config, "algo": algo, "m": m, "sigma": sigma, "kernel": kernel, "ms": round(ms, 4),
+        cell = {"config": config, "algo": algo, "m": m, "sigma": sigma, "kernel": kernel, "ms": round(ms, 4), "gib": round(n / (1 << 30), 3),
                 "frac": round(n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "count_ok": bool(ok)}
         if len(kernels) > 1:
             cell["kernels"] = dict(kernels)
@@ -601,7 +604,7 @@ def run_sweep(text128, device):
             cell["own_kernel"] = True  # smartgpu_tune(0,1): the algorithm's own kernel, not the plan's choice
         return cell
 
-    def cells_for(config, text, sigma, algos, ms, unit=None):
+    def cells_for(config, text, sigma, algos, ms, unit=None, n=n):
         for m in ms:
             if unit is None:
                 pats = [text.pattern(splitmix64(PATTERN_SALT + 4096 * j + m) % (n - m), m) for j in range(J)]
@@ -610,10 +613,10 @@ def run_sweep(text128, device):
             for algo in algos:
                 if m < smart_amd.MIN_M.get(algo, 1):
                     continue
-                c = time_cell(config, text, sigma, algo, m, pats, own=False)
+                c = time_cell(config, text, sigma, algo, m, pats, False, n)
                 cells.append(c)
                 if c["kernel"] != OWN_KERNEL[algo] or "kernels" in c:
-                    cells.append(time_cell(config, text, sigma, algo, m, pats, own=True))
+                    cells.append(time_cell(config, text, sigma, algo, m, pats, True, n))
 
     own128 = text128 is None
     if own128:
@@ -625,17 +628,15 @@ def run_sweep(text128, device):
     for sigma in (4, 2):
         t = Text.generate(SEED, sigma, n, device=device)
         cells_for(3, t, sigma, ("so", "bndm"), (2, 4, 8, 16, 32, 64))
-        if sigma == 2:
-            cells_for(5, t, sigma, ("hor", "bm", "kmp", "so", "epsm"), SETS_H_25)
         t.free()
-    for sigma in (32, 256):
-        t = Text.generate(SEED, sigma, n, device=device)
-        cells_for(5, t, sigma, ("hor", "bm", "kmp", "so", "epsm"), SETS_H_25)
+    for sigma in (2, 32, 256):
+        t = Text.generate(SEED, sigma, BIG, device=device)
+        cells_for(5, t, sigma, ("hor", "bm", "kmp", "so", "epsm"), SETS_H_25, n=BIG)
         t.free()
     from smart_amd import corpus
     unit = corpus.english_unit()
-    t = Text.upload_tiled(unit, n, device=device)
-    cells_for(4, t, "english", ("hor", "bm", "kmp", "so", "bndm", "epsm"), SETS_H_25, unit=unit)
+    t = Text.upload_tiled(unit, BIG, device=device)
+    cells_for(4, t, "english", ("hor", "bm", "kmp", "so", "bndm", "epsm"), SETS_H_25, unit=unit, n=BIG)
     t.free()
     bad = [c for c in cells if not c["count_ok"]]
     if bad:
@@ -650,12 +651,12 @@ def run_sweep(text128, device):
                          "plan_choice_all_cells": min(c["frac"] for c in cells if not c.get("own_kernel")),
                          # what the plans route AWAY from: a skip loop on a binary text shifts by a byte or two
                          "own_kernel_cells": min([c["frac"] for c in cells if c.get("own_kernel")] or [None])},
-            "note": "config = BASELINE.json configuration the cell belongs to (4: the English unit tiled to 1 GiB, 5: one 1 GiB "
-                    "shard per alphabet; their 4 GiB sizes: profiles/ sweeps, tests/test_configs_gpu.py); "
-                    "1 GiB per cell; ms = the median of %d rounds, each %d patterns between two HIP events; frac = 2^30 B / ms / 8 TB/s; "
+            "note": "config = BASELINE.json configuration the cell belongs to (2, 3: 1 GiB texts; 4: the English unit tiled to %g GiB; 5: one "
+                    "%g GiB shard per alphabet — the sizes BASELINE.json states per GPU; 32 GiB on one GPU: tests/test_configs_gpu.py); "
+                    "gib = the cell's text size; ms = the median of %d rounds, each %d patterns between two HIP events; frac = text bytes / ms / 8 TB/s; "
                     "own_kernel = measured again with smartgpu_tune(0,1) because the plan rerouted the pattern; "
                     "count_ok = equal to the count of a kernel of another family (reference kernels used: %s)"
-                    % (REPS, J, dict(checked_by))}
+                    % (BIG_GIB, BIG_GIB, REPS, J, dict(checked_by))}
 
 
 if __name__ == "__main__":
