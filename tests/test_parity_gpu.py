@@ -806,6 +806,36 @@ def test_bndm_gram_tables_on_texts_of_at_most_four_values(oracle):
     text.free()
 
 
+def test_occurrence_sums_of_large_grids_are_staged_and_cleared(oracle):
+    """flush_hits (dev_common.hpp): a grid of 1024+ workgroups adds its workgroups' sums to 64 staging slots in the text's
+    front pad, the last arrival of a slot forwards it and clears it.  Occurrences in EVERY workgroup (two values, m = 2:
+    a quarter of all positions), the same text searched again and again by kernels of every family, whole and in part,
+    one pattern and a set in one grid (which adds directly): every count equals the oracle's on a slice and the
+    first search's on the whole — nothing left behind in a slot, nothing counted twice."""
+    from smart_amd import engine
+    n = 300_000_000
+    text = Text.generate(SEED2, 2, n)
+    T = oracle.gen_text(SEED2, 2, 0, 4_000_000)
+    assert bytes(text.read(0, 4096)) == T[:4096].tobytes()
+    for m in (2, 3, 9):
+        P = T[1000:1000 + m].copy()
+        small = oracle.search("bf", P, T)
+        engine.tune(0, 1)  # every algorithm on its own kernel: tiles (hor, bm, bndm), runs (so, kmp), packed (epsm)
+        try:
+            whole = {}
+            for rep in range(3):
+                for a in ("epsm", "hor", "bm", "bndm", "so", "kmp"):
+                    c = smart_amd.search(a, P, text)[0]
+                    assert whole.setdefault(m, c) == c, (a, m, rep, c, whole)
+                    assert smart_amd.search(a, P, text, off=0, n=4_000_000)[0] == small, (a, m, rep)
+            pats = [P, T[5000:5000 + m].copy(), T[77:77 + m].copy()]
+            counts, _, _, _ = smart_amd.search_batch("epsm", pats, text)
+            assert counts[0] == whole[m] and all(smart_amd.search("so", p, text)[0] == c for p, c in zip(pats, counts.tolist())), (m, counts)
+        finally:
+            engine.tune(0, 0)
+    text.free()
+
+
 def test_text_alphabet():
     """What a text consists of is taken on the device when it is created (smartgpu_text_alphabet): uploaded, tiled and
     generated texts, lengths that are no multiple of the 16-byte loads, the empty text."""
