@@ -40,12 +40,15 @@ __device__ __forceinline__ void gram_skip_scan(const ScanArgs& a, uint64_t tile_
     static_assert(L == 64 && THREADS == 256 && ((GRAM == 1 && Q == 8) || (GRAM == 2 && Q == 4)), "a gram is 8 one-bit or 4 two-bit symbols");
     const uint32_t m = a.m;  // m >= Q (the launchers)
     uint32_t* E = reinterpret_cast<uint32_t*>(smem);
-    // LDS: E[256] | 32 pattern bytes | the flag | BM: u16 gsT[40], gs[0], the parked windows' safe shift (84 bytes) | column tile
-    constexpr uint32_t kPat = 1024, kGs = kPat + 48, kTxt = BM ? 1168u : 1072u;
+    // LDS: E[256] | column tile | 32 pattern bytes | the flag | BM: u16 gsT[40], gs[0], the parked windows' safe shift (84 bytes)
+    // (the tile at a multiple of 256 — its rows are then ds_read2st64's immediate offsets, no add on the lane's address —, the
+    // pattern's bytes, the flag and BM's shifts BEHIND it: the LDS of a workgroup is what it was, six of them per CU)
+    constexpr uint32_t kTxt = 1024, kPat = kTxt + ColTile<THREADS>::bytes(), kGs = kPat + 48;
     uint8_t* txt = smem + kTxt;
     // the text's codes, from the first words of the text's own allocation (TextCodes, kernels.hpp)
     const uint32_t* const tc = reinterpret_cast<const uint32_t*>(a.text - kFrontPad);
     const uint32_t cshift = GRAM == 2 ? tc[0] : tc[2] & 0xFFu;  // two-bit codes: (c >> shift) & 3; one-bit: (c >> bit) & 1
+    const uint32_t rot4 = (cshift + 30u) & 31u;                 // GRAM 2: rotate right by shift - 2 (left by 2 - shift): a byte's code at its bits 2-3
     const uint32_t symtab = GRAM == 2 ? tc[1] : tc[2] >> 8;     // the byte value of each code
     constexpr uint32_t kBits = GRAM == 2 ? 2u : 1u, kMask = GRAM == 2 ? 3u : 1u;
     uint32_t* const foreign = reinterpret_cast<uint32_t*>(smem + kPat + 32);  // set if a pattern byte is no symbol of the text
@@ -141,29 +144,33 @@ __device__ __forceinline__ void gram_skip_scan(const ScanArgs& a, uint64_t tile_
             x0 = lo < hi ? (uint32_t)(lo - seg) : 0u;
             x1 = lo < hi ? (uint32_t)(hi - seg) : 0u;
         }
-        uint32_t e = 32u + x0;
-        const uint32_t ehi = 32u + x1;
+        // The walk runs on pl = e - (Q - 1), the position of the gram's FIRST byte (e: the window's end): that is what addresses the
+        // column and shifts the two dwords apart, and the loop is bound by what it issues (no e - 3, no + 32 for the tile's
+        // offset, the codes scaled by 4 as they are extracted: the dot product is the table's byte offset).
+        uint32_t pl = 32u + x0 - (Q - 1);
+        const uint32_t plhi = 32u + x1 - (Q - 1);
         uint32_t parked_e = 0;  // LONG: the window end of the tile's first candidate (0: none; e >= 32)
-        while (e < ehi) {
-            const uint32_t pl = e - (Q - 1);
+        while (pl < plhi) {
             const uint32_t at = col4 + (pl >> 2) * CT::RS;
             const uint32_t w0 = *(const lds_u32_t*)(size_t)at;
             const uint32_t w1 = *(const lds_u32_t*)(size_t)(at + CT::RS);
             const uint32_t x_lo = __builtin_amdgcn_alignbyte(w1, w0, pl);
-            uint32_t g;
+            uint32_t g4;  // 4 * gram: E's byte offset
             if (GRAM == 2) {
-                g = __builtin_amdgcn_udot4((x_lo >> cshift) & 0x03030303u, 0x40100401u, 0u, false);
+                // the two-bit codes at bits 2-3 of their bytes (a rotation by shift - 2, either way), weights 1, 4, 16, 64
+                g4 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbit(x_lo, x_lo, rot4) & 0x0C0C0C0Cu, 0x40100401u, 0u, false);
             } else {
                 const uint32_t w2 = *(const lds_u32_t*)(size_t)(at + 2 * CT::RS);
                 const uint32_t x_hi = __builtin_amdgcn_alignbyte(w2, w1, pl);
-                g = __builtin_amdgcn_udot4((x_lo >> cshift) & 0x01010101u, 0x08040201u, 0u, false) |
-                    (__builtin_amdgcn_udot4((x_hi >> cshift) & 0x01010101u, 0x08040201u, 0u, false) << 4);
+                g4 = __builtin_amdgcn_udot4((x_lo >> cshift) & 0x01010101u, 0x20100804u, 0u, false) |
+                     (__builtin_amdgcn_udot4((x_hi >> cshift) & 0x01010101u, 0x08040201u, 0u, false) << 6);
             }
-            const uint32_t ent = *(const lds_u32_t*)(size_t)(4u * g);
+            const uint32_t ent = *(const lds_u32_t*)(size_t)g4;
             uint32_t cand_shift = 1;  // BM: what a candidate moves by
             (void)cand_shift;
-            if (__any((int32_t)ent < 0)) {  // the window's last gram is P's somewhere in the wave: hor.c:41-46 for those lanes
+            {   // the window's last gram is P's: hor.c:41-46 for those lanes (a wave without one skips the block)
                 if ((int32_t)ent < 0) {
+                    const uint32_t e = pl + (Q - 1);
                     const uint32_t ws = e - (Q - 1) - nlds;
                     if (!BM) {
                         // the nlds bytes in front of the gram against the pattern's, a dword at a time
@@ -211,7 +218,7 @@ __device__ __forceinline__ void gram_skip_scan(const ScanArgs& a, uint64_t tile_
                     }
                 }
             }
-            e += (BM && (int32_t)ent < 0) ? cand_shift : ent & 0x7FFFFFFFu;  // hor.c:49 on grams
+            pl += (BM && (int32_t)ent < 0) ? cand_shift : ent & 0x7FFFFFFFu;  // hor.c:49 on grams
         }
         if (LONG && __any(parked_e != 0)) hits += wave_verify(parked_e != 0, a.text + seg + (parked_e - 32u) - (m - 1), a.blob, lds_from);
     }

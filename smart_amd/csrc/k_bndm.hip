@@ -21,7 +21,7 @@ namespace sg {
 // compared with P[0..w-Q) in LDS; m > 32: the rest in memory, first candidate of a tile parked for wave_verify).  The
 // mask loop below reads on while factors are alive and, forgetting what it saw inside a gram, moves a fully read
 // window by 1 — the lanes that meet such windows set their wave's trip count (rand2 m = 16: 0.35, here the shift is ~14).
-// LDS: u32 E[256] (first B: the masks, left-aligned) | P[0..32) | column tile
+// LDS: u32 E[256] (first B: the masks, left-aligned) | column tile | P[0..32)
 // ---------------------------------------------------------------------------
 template <int THREADS, int L, bool LONG, int Q, int GRAM>
 __device__ __forceinline__ void bndm_gram(const ScanArgs& a, uint64_t tile_first, uint32_t ntiles, uint8_t* smem)
@@ -31,7 +31,9 @@ __device__ __forceinline__ void bndm_gram(const ScanArgs& a, uint64_t tile_first
     static_assert(L == 64 && THREADS == 256 && ((GRAM == 1 && Q == 8) || (GRAM == 2 && Q == 4)), "a gram is 8 one-bit or 4 two-bit symbols; thread g derives entry g");
     const uint32_t m = a.m, w = m < 32 ? m : 32;  // w >= Q (launch_bndm)
     uint32_t* E = reinterpret_cast<uint32_t*>(smem);
-    constexpr uint32_t kPat = 1024, kTxt = 1056;
+    // (the tile at a multiple of 256 — its rows are then ds_read2st64's immediate offsets, no add on the lane's address —, the
+    // pattern's bytes BEHIND it: 1056 bytes + the tile as before, six workgroups per CU)
+    constexpr uint32_t kTxt = 1024, kPat = kTxt + ColTile<THREADS>::bytes();
     uint8_t* txt = smem + kTxt;
     // the text's codes, from the first words of the text's own allocation (TextCodes, kernels.hpp)
     const uint32_t* const tc = reinterpret_cast<const uint32_t*>(a.text - kFrontPad);
@@ -86,6 +88,7 @@ __device__ __forceinline__ void bndm_gram(const ScanArgs& a, uint64_t tile_first
         return __builtin_amdgcn_alignbyte(*(const lds_u32_t*)(size_t)(at + CT::RS), *(const lds_u32_t*)(size_t)at, p);
     };
     const uint32_t nrest = w - Q;  // bytes of the window in front of its last gram
+    const uint32_t rot4 = (cshift + 30u) & 31u;  // GRAM 2: rotate right by shift - 2 (left by 2 - shift): a byte's code at its bits 2-3
     for (; t < t_end; t += gridDim.x) {
         const uint64_t tile0 = t * TB;
         __syncthreads();
@@ -100,45 +103,48 @@ __device__ __forceinline__ void bndm_gram(const ScanArgs& a, uint64_t tile_first
             x0 = lo < hi ? (uint32_t)(lo - seg) : 0u;
             x1 = lo < hi ? (uint32_t)(hi - seg) : 0u;
         }
-        uint32_t e = 32u + x0;
-        const uint32_t ehi = 32u + x1;
+        // The walk runs on pl = e - (Q - 1), the position of the gram's FIRST byte (e: the window's end): that is what addresses the
+        // column and shifts the two dwords apart, and the loop is bound by what it issues — 14 vector instructions per window
+        // before, 11 now (no e - 3, no + 32 for the tile's offset, the codes scaled by 4 as they are extracted: the dot product is
+        // the table's byte offset).
+        uint32_t pl = 32u + x0 - (Q - 1);
+        const uint32_t plhi = 32u + x1 - (Q - 1);
         uint32_t parked_e = 0;  // LONG: the window end of the tile's first candidate whose 32 bytes matched (0: none; e >= 32)
-        while (e < ehi) {
-            const uint32_t pl = e - (Q - 1);
+        while (pl < plhi) {
             const uint32_t at = col4 + (pl >> 2) * CT::RS;
             const uint32_t w0 = *(const lds_u32_t*)(size_t)at;
             const uint32_t w1 = *(const lds_u32_t*)(size_t)(at + CT::RS);
             const uint32_t x_lo = __builtin_amdgcn_alignbyte(w1, w0, pl);
-            uint32_t g;
+            uint32_t g4;  // 4 * gram: E's byte offset
             if (GRAM == 2) {
-                g = __builtin_amdgcn_udot4((x_lo >> cshift) & 0x03030303u, 0x40100401u, 0u, false);
+                // the two-bit codes at bits 2-3 of their bytes (a rotation by shift - 2, either way), weights 1, 4, 16, 64
+                g4 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbit(x_lo, x_lo, rot4) & 0x0C0C0C0Cu, 0x40100401u, 0u, false);
             } else {
                 const uint32_t w2 = *(const lds_u32_t*)(size_t)(at + 2 * CT::RS);
                 const uint32_t x_hi = __builtin_amdgcn_alignbyte(w2, w1, pl);
-                g = __builtin_amdgcn_udot4((x_lo >> cshift) & 0x01010101u, 0x08040201u, 0u, false) |
-                    (__builtin_amdgcn_udot4((x_hi >> cshift) & 0x01010101u, 0x08040201u, 0u, false) << 4);
+                g4 = __builtin_amdgcn_udot4((x_lo >> cshift) & 0x01010101u, 0x20100804u, 0u, false) |
+                     (__builtin_amdgcn_udot4((x_hi >> cshift) & 0x01010101u, 0x08040201u, 0u, false) << 6);
             }
-            const uint32_t ent = *(const lds_u32_t*)(size_t)(4u * g);
+            const uint32_t ent = *(const lds_u32_t*)(size_t)g4;
             if (!LONG && nrest == 0) {  // (uniform) the window is one gram
                 hits += ent >> 31;
-            } else if (__any((int32_t)ent < 0)) {  // a candidate somewhere in the wave: one gram in 256 on random text
-                if ((int32_t)ent < 0) {
-                    // the nrest bytes in front of the gram against P[0..nrest), a dword at a time
-                    const uint32_t ws = e - (w - 1);
-                    bool ok = true;
-                    for (uint32_t d = 0; d < nrest; d += 4) {
-                        const uint32_t nb = nrest - d < 4 ? nrest - d : 4u;
-                        const uint32_t mask = nb == 4 ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
-                        ok = ok && ((text4(ws + d) ^ *(const lds_u32_t*)(size_t)(kPat + d)) & mask) == 0;
-                    }
-                    if (ok) {
-                        if (!LONG) ++hits;
-                        else if (parked_e == 0) parked_e = e;
-                        else hits += global_equal(a.text + seg + (e - 32u) + 1, a.blob + w, m - w);  // = text + s + w
-                    }
+            } else if (__any((int32_t)ent < 0) && (int32_t)ent < 0) {  // a candidate: one gram in 256 on random text
+                // the nrest bytes in front of the gram against P[0..nrest), a dword at a time
+                const uint32_t e = pl + (Q - 1);
+                const uint32_t ws = e - (w - 1);
+                bool ok = true;
+                for (uint32_t d = 0; d < nrest; d += 4) {
+                    const uint32_t nb = nrest - d < 4 ? nrest - d : 4u;
+                    const uint32_t mask = nb == 4 ? 0xFFFFFFFFu : (1u << (8u * nb)) - 1u;
+                    ok = ok && ((text4(ws + d) ^ *(const lds_u32_t*)(size_t)(kPat + d)) & mask) == 0;
+                }
+                if (ok) {
+                    if (!LONG) ++hits;
+                    else if (parked_e == 0) parked_e = e;
+                    else hits += global_equal(a.text + seg + (e - 32u) + 1, a.blob + w, m - w);  // = text + s + w
                 }
             }
-            e += ent & 0xFFu;
+            pl += ent & 0xFFu;
         }
         if (LONG && __any(parked_e != 0)) hits += wave_verify(parked_e != 0, a.text + seg + (parked_e - 32u) + 1, a.blob + w, m - w);
     }
